@@ -1,0 +1,162 @@
+/*
+ * tstwo_hip.h — C ABI of libtstwo_hip.so, the MI355X (gfx950) backend for tstwo's data-parallel
+ * hot path.  This is the drop-in boundary: exactly the entry points a `HipBackend` for
+ * teddyjfpender/tstwo binds with bun:ffi (INTEGRATION.md shows the TypeScript stub).  The reference
+ * has no FFI today; each entry point below cites the TypeScript interface/function it replaces
+ * (paths relative to packages/core/src of the reference).
+ *
+ * Conventions
+ *  - Every function returns 0 on success, nonzero on failure; tstwo_last_error() then holds the
+ *    reference's own error text where the reference throws (e.g. "0 has no inverse",
+ *    "length is not power of two", "Not enough twiddles!") so the wrapper can `throw new Error(msg)`.
+ *  - Columns are plain little-endian uint32 device buffers holding canonical M31 values in [0, P),
+ *    P = 2^31-1 (M31.intoSlice layout, fields/m31.ts:272-284).  QM31 / SecureColumnByCoords data
+ *    is struct-of-arrays: 4 coordinate columns (fields/secure_columns.ts:124).  Hashes are 32-byte
+ *    Blake2s digests, layers are arrays of digests (vcs/blake2_hash.ts:5-49).
+ *  - "dev" pointers are device addresses (from tstwo_malloc, or any HIP allocation of the same
+ *    process, e.g. a torch tensor's data_ptr()).  `const uint32_t *const *cols` style arguments are
+ *    HOST arrays of device pointers, borrowed for the duration of the call.
+ *  - Work is enqueued on one HIP stream per process (tstwo_set_stream to borrow the caller's).
+ *    Calls that hand results to host memory synchronise; the others are asynchronous and ordered
+ *    on that stream; tstwo_sync() drains it.  Thread-compatible: the caller serialises calls.
+ *  - No CPU fallback exists: every entry point fails with an error if no GPU is present.
+ */
+#ifndef TSTWO_HIP_H
+#define TSTWO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSTWO_OK 0
+#define TSTWO_ERR_HIP 1            /* HIP runtime failure (text has the hipError string) */
+#define TSTWO_ERR_ZERO_INVERSE 2   /* "0 has no inverse"                      fields/m31.ts:139 */
+#define TSTWO_ERR_NOT_POW2 3       /* "length is not power of two"            backend/cpu/index.ts:65 */
+#define TSTWO_ERR_TWIDDLES 4       /* "Not enough twiddles!"                  poly/utils.ts:86 */
+#define TSTWO_ERR_TOO_SMALL 5      /* "fold_line: Evaluation too small, ..."  fri.ts:127 */
+#define TSTWO_ERR_LEN_MISMATCH 6   /* "fold_circle_into_line: Length mismatch ..." fri.ts:168 */
+#define TSTWO_ERR_BAD_ARG 7
+#define TSTWO_ERR_LOG_SIZE 8       /* "log size too small"                    backend/cpu/circle.ts:72 */
+
+/* ---------------------------------------------------------------- lifecycle / plumbing */
+int tstwo_init(int device);                 /* select GPU `device`, create the stream; idempotent */
+int tstwo_shutdown(void);
+const char *tstwo_last_error(void);
+const char *tstwo_version(void);
+int tstwo_device_count(int *out);
+int tstwo_device_name(char *buf, size_t buflen);
+int tstwo_set_stream(void *hip_stream);     /* borrow a caller stream (NULL = back to the library's) */
+int tstwo_sync(void);
+int tstwo_malloc(void **dev, size_t bytes);
+int tstwo_free(void *dev);
+int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);     /* synchronous */
+int tstwo_download(void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
+int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes);        /* async d2d */
+int tstwo_zero(void *dev, size_t bytes);                                  /* async; Column.zeros, backend/index.ts:56 */
+/* HIP events on the library's stream (bench.py times kernels with these) */
+int tstwo_event_create(void **ev);
+int tstwo_event_record(void *ev);
+int tstwo_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);    /* synchronises on ev_stop */
+int tstwo_event_destroy(void *ev);
+
+/* ---------------------------------------------------------------- field column ops
+ * M31.add/sub/mul/neg applied per element (fields/m31.ts:147-173); bench/m31.bench.ts workload. */
+int tstwo_m31_add(const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+int tstwo_m31_sub(const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+int tstwo_m31_mul(const uint32_t *a, const uint32_t *b, uint32_t *out, size_t n);
+int tstwo_m31_neg(const uint32_t *a, uint32_t *out, size_t n);
+/* batchInverse (fields/fields.ts:66-207).  Result = elementwise inverse; any zero input fails with
+ * TSTWO_ERR_ZERO_INVERSE like the reference's single final inverse().  Synchronises (error flag). */
+int tstwo_m31_batch_inverse(const uint32_t *in, uint32_t *out, size_t n);
+int tstwo_cm31_batch_inverse(const uint32_t *const in[2], uint32_t *const out[2], size_t n);
+int tstwo_qm31_batch_inverse(const uint32_t *const in[4], uint32_t *const out[4], size_t n);
+/* QM31.mul / QM31.add per element on SoA columns (fields/qm31.ts:168-233) */
+int tstwo_qm31_mul(const uint32_t *const a[4], const uint32_t *const b[4], uint32_t *const out[4], size_t n);
+/* AccumulationOps.accumulate: col[i] += other[i] (backend/cpu/accumulation.ts:38-49) */
+int tstwo_secure_accumulate(uint32_t *const col[4], const uint32_t *const other[4], size_t n);
+
+/* ---------------------------------------------------------------- ColumnOps.bitReverseColumn
+ * In-place bit-reversal permutation of each column (backend/index.ts:20, backend/cpu/index.ts:62-79).
+ * n == 0 or not a power of two -> TSTWO_ERR_NOT_POW2. */
+int tstwo_bit_reverse(uint32_t *const *cols, size_t n_cols, size_t n);
+
+/* ---------------------------------------------------------------- PolyOps.precomputeTwiddles
+ * Twiddle tree of the coset (initial index `coset_initial`, log size `log_size`): 2^log_size words
+ * (backend/cpu/circle.ts:210-239, poly/twiddles.ts:10-29).  itw = elementwise inverse (may be NULL).
+ * Generated on the device. */
+int tstwo_twiddles_build(uint32_t coset_initial, uint32_t log_size, uint32_t *tw, uint32_t *itw);
+
+/* ---------------------------------------------------------------- PolyOps.evaluate / interpolate
+ * Circle FFT over n_cols independent columns of 2^log_size words, in place, bit-reversed evaluation
+ * order (backend/cpu/circle.ts:84-134 / :136-207).  The domain is CircleDomain(half coset =
+ * (half_initial, log_size-1)); tw / itw is the (inverse) twiddle tree of a root coset of log
+ * tw_log of which that half coset is a doubling (the wrapper checks is_doubling_of and throws
+ * "twiddle tree mismatch").  evaluate expects coefficients already extended to 2^log_size
+ * (tstwo_poly_extend).  The true transform (Rust-exact) is computed; the reference's log_size==3
+ * output swap (circle.ts:123-131) is offered by the wrapper as a compat option, not here. */
+int tstwo_cfft_evaluate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,
+                        const uint32_t *tw, uint32_t tw_log);
+int tstwo_cfft_interpolate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,
+                           const uint32_t *itw, uint32_t tw_log);
+/* PolyOps.extend (circle.ts:71-82): dst[0..2^log_dst) = src[0..2^log_src) zero-padded.
+ * log_dst < log_src -> TSTWO_ERR_LOG_SIZE ("log size too small"). */
+int tstwo_poly_extend(const uint32_t *src, uint32_t log_src, uint32_t *dst, uint32_t log_dst);
+/* PolyOps.eval_at_point (circle.ts:52-69): point and result are QM31 as 4 host words. */
+int tstwo_eval_at_point(const uint32_t *coeffs, uint32_t log_size, const uint32_t point_x[4],
+                        const uint32_t point_y[4], uint32_t out[4]);
+
+/* ---------------------------------------------------------------- FriOps (fri.ts:93-110)
+ * Twiddles come from the inverse twiddle tree `itw` (root coset log tw_log) — a FRI fold is one
+ * inverse-CFFT layer followed by f0 + alpha*f1.
+ * fold_line (fri.ts:120-152): in = 2^log_n rows on LineDomain(coset of log log_n, a doubling of the
+ * tree's root), out = 2^(log_n-1) rows.  log_n == 0 -> TSTWO_ERR_TOO_SMALL. */
+int tstwo_fri_fold_line(const uint32_t *const in[4], uint32_t log_n, const uint32_t *itw, uint32_t tw_log,
+                        const uint32_t alpha[4], uint32_t *const out[4]);
+/* fold_circle_into_line (fri.ts:162-192): src = 2^log_n rows on a CircleDomain whose half coset is a
+ * doubling of the tree's root; dst (dst_len rows) is updated in place: dst*alpha^2 + (alpha*f1 + f0).
+ * dst_len != 2^(log_n-1) -> TSTWO_ERR_LEN_MISMATCH. */
+int tstwo_fri_fold_circle_into_line(uint32_t *const dst[4], size_t dst_len, const uint32_t *const src[4],
+                                    uint32_t log_n, const uint32_t *itw, uint32_t tw_log, const uint32_t alpha[4]);
+/* Variants taking the n/2 per-output inverse twiddles explicitly (domains that are not a doubling
+ * of a precomputed tree, and log_n < 3 for the circle fold). */
+int tstwo_fri_fold_line_tw(const uint32_t *const in[4], uint32_t log_n, const uint32_t *inv_x,
+                           const uint32_t alpha[4], uint32_t *const out[4]);
+int tstwo_fri_fold_circle_into_line_tw(uint32_t *const dst[4], size_t dst_len, const uint32_t *const src[4],
+                                       uint32_t log_n, const uint32_t *inv_y, const uint32_t alpha[4]);
+/* decompose (backend/cpu/fri.ts:97-164): lambda (host, 4 words) and g = f -/+ lambda per half. */
+int tstwo_fri_decompose(const uint32_t *const in[4], size_t n, uint32_t *const out[4], uint32_t lambda[4]);
+
+/* ---------------------------------------------------------------- MerkleOps (vcs/ops.ts:16-26)
+ * commitOnLayer: node i = Blake2s( [prev[2i] || prev[2i+1]]  ||  LE32(cols[0][i]) || ... ), i < 2^log_size
+ * (vcs/blake2_merkle.ts:9-24).  prev = NULL for the bottom layer.  out: 2^log_size * 32 bytes (device). */
+int tstwo_merkle_commit_layer(uint32_t log_size, const uint8_t *prev, const uint32_t *const *cols,
+                              size_t n_cols, uint8_t *out);
+/* MerkleProver.commit (vcs/prover.ts:13-30): columns of mixed log sizes join at their layer (input
+ * order kept within a size class).  layers (device) receives every layer, root first: layer k (2^k
+ * digests) starts at byte offset 32*(2^k - 1); total 32*(2^(max_log+1) - 1) bytes.  root (host, 32 B)
+ * may be NULL (then nothing is synchronised).  n_cols == 0 -> one hash of the empty message. */
+int tstwo_merkle_commit(const uint32_t *const *cols, const uint32_t *log_sizes, size_t n_cols,
+                        uint8_t *layers, uint8_t root[32]);
+size_t tstwo_merkle_layers_bytes(uint32_t max_log);
+
+/* ---------------------------------------------------------------- QuotientOps
+ * accumulateQuotients row loop (backend/cpu/quotients.ts:52-116,160-178) with the per-batch constants
+ * computed by the wrapper (quotientConstants, quotients.ts:124-191; constraints.ts:117-128):
+ *   batch b covers entries [batch_off[b], batch_off[b+1]) of col_idx / abc;
+ *   abc[3*j..3*j+2] = (alpha^j a, alpha^j b, alpha^j c) as QM31 (4 words each);
+ *   den_b(row) = (prx[b] - p.x) * piy[b] - (pry[b] - p.y) * pix[b]  in CM31 (2 words each);
+ *   acc = acc * batch_coeff[b] + num_b * den_b^-1.
+ * Domain = CircleDomain(half coset (half_initial, log_size-1)), rows in bit-reversed order.
+ * All constant arrays are host memory.  A vanishing denominator fails with TSTWO_ERR_ZERO_INVERSE. */
+int tstwo_quotients_accumulate(uint32_t half_initial, uint32_t log_size, const uint32_t *const *cols,
+                               size_t n_cols, size_t n_batches, const uint32_t *batch_off,
+                               const uint32_t *col_idx, const uint32_t *abc, const uint32_t *batch_coeff,
+                               const uint32_t *prx, const uint32_t *pry, const uint32_t *pix,
+                               const uint32_t *piy, uint32_t *const out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,442 @@
+"""-m gpu parity tests: the HIP path, called through the C ABI (include/tstwo_hip.h), against the CPU
+oracle on the same seeded inputs — bit-exact (all arithmetic is integer)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import P, column, rand_column
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from tstwo_amd import _lib as L  # noqa: E402
+from gpu_util import dev, dev_empty, host, p4, ptrs, vp  # noqa: E402
+
+OL = orc.lib()
+
+
+def half_odds(k):
+    return OL.orc_half_odds_initial(k)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    L.init(0)
+    yield
+    L.sync()
+
+
+# ------------------------------------------------------------------ field columns
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 255, 256, 1 << 12, (1 << 16) + 3, 1 << 20])
+def test_m31_elementwise(n):
+    a, b = rand_column(1, n), rand_column(2, n)
+    # include the edge values 0 and P-1
+    a[0], b[0] = 0, P - 1
+    if n > 2:
+        a[1], b[1] = P - 1, P - 1
+    da, db, do = dev(a), dev(b), dev_empty(n)
+    for op in ("add", "sub", "mul"):
+        L.call(f"tstwo_m31_{op}", vp(da), vp(db), vp(do), n)
+        assert (host(do, n) == orc.col_op(op, a, b)).all(), op
+    L.call("tstwo_m31_neg", vp(da), vp(do), n)
+    assert (host(do, n) == orc.col_op("neg", a)).all()
+
+
+def test_m31_elementwise_unaligned():
+    n = 1001
+    a, b = rand_column(3, n + 1), rand_column(4, n + 1)
+    da, db, do = dev(a), dev(b), dev_empty(n + 1)
+    L.call("tstwo_m31_mul", vp(da, 4), vp(db, 4), vp(do, 4), n)
+    assert (host(do, n + 1)[1:] == orc.col_op("mul", a[1:], b[1:])).all()
+
+
+@pytest.mark.parametrize("n", [1, 4, 5, 17, 1000, 1 << 12, 1 << 20])
+def test_m31_batch_inverse(n):
+    a = rand_column(5, n, nonzero=True)
+    da, do = dev(a), dev_empty(n)
+    L.call("tstwo_m31_batch_inverse", vp(da), vp(do), n)
+    assert (host(do, n) == orc.m31_batch_inverse(a)).all()
+
+
+def test_batch_inverse_zero_is_an_error():
+    a = rand_column(6, 4096, nonzero=True)
+    a[1234] = 0
+    da, do = dev(a), dev_empty(4096)
+    with pytest.raises(L.TstwoError, match="0 has no inverse"):
+        L.call("tstwo_m31_batch_inverse", vp(da), vp(do), 4096)
+    a[1234] = 7   # the flag must have been cleared
+    da.upload(a)
+    L.call("tstwo_m31_batch_inverse", vp(da), vp(do), 4096)
+    assert (host(do, 4096) == orc.m31_batch_inverse(a)).all()
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 1000, 1 << 14])
+def test_qm31_batch_inverse_and_mul(n):
+    a = [rand_column(10 + k, n, nonzero=True) for k in range(4)]
+    b = [rand_column(20 + k, n) for k in range(4)]
+    da, db = [dev(c) for c in a], [dev(c) for c in b]
+    do = [dev_empty(n) for _ in range(4)]
+    L.call("tstwo_qm31_batch_inverse", p4(da), p4(do), n)
+    exp = orc.qm31_batch_inverse(a)
+    for k in range(4):
+        assert (host(do[k], n) == exp[k]).all()
+    L.call("tstwo_qm31_mul", p4(da), p4(db), p4(do), n)
+    exp = orc.qm31_col_mul(a, b)
+    for k in range(4):
+        assert (host(do[k], n) == exp[k]).all()
+    L.call("tstwo_secure_accumulate", p4(da), p4(db), n)
+    exp = orc.accumulate(a, b)
+    for k in range(4):
+        assert (host(da[k], n) == exp[k]).all()
+    # zero element -> reference error text
+    z = [c.copy() for c in a]
+    for k in range(4):
+        z[k][n // 2] = 0
+    dz = [dev(c) for c in z]
+    with pytest.raises(L.TstwoError, match="0 has no inverse"):
+        L.call("tstwo_qm31_batch_inverse", p4(dz), p4(do), n)
+
+
+def test_cm31_batch_inverse():
+    n = 3000
+    a = [rand_column(30 + k, n, nonzero=True) for k in range(2)]
+    da, do = [dev(c) for c in a], [dev_empty(n) for _ in range(2)]
+    L.call("tstwo_cm31_batch_inverse", L.P2(da[0].ptr, da[1].ptr), L.P2(do[0].ptr, do[1].ptr), n)
+    got = [host(do[k], n) for k in range(2)]
+    for i in range(0, n, 37):
+        r = orc.CM31()
+        assert OL.orc_cm31_inverse(orc.CM31(int(a[0][i]), int(a[1][i])), r) == 0
+        assert (int(got[0][i]), int(got[1][i])) == (r.a, r.b)
+
+
+# ------------------------------------------------------------------ bit reverse
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 8, 13, 20])
+def test_bit_reverse(log_n):
+    n = 1 << log_n
+    cols = [rand_column(40 + c, n) for c in range(3)]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_bit_reverse", ptrs(d), 3, n)
+    for c in range(3):
+        assert (host(d[c], n) == orc.bit_reverse(cols[c])).all()
+
+
+@pytest.mark.parametrize("n", [0, 3, 6, 1000])
+def test_bit_reverse_not_pow2(n):
+    d = [dev(np.zeros(max(n, 1), dtype=np.uint32))]
+    with pytest.raises(L.TstwoError, match="length is not power of two"):
+        L.call("tstwo_bit_reverse", ptrs(d), 1, n)
+
+
+# ------------------------------------------------------------------ twiddles
+def build_twiddles(log, initial=None):
+    initial = half_odds(log) if initial is None else initial
+    n = 1 << log
+    tw, itw = dev_empty(n), dev_empty(n)
+    L.call("tstwo_twiddles_build", initial, log, vp(tw), vp(itw))
+    return tw, itw
+
+
+@pytest.mark.parametrize("log", [0, 1, 2, 3, 5, 8, 12, 16])
+def test_twiddles(log, golden):
+    tw, itw = build_twiddles(log)
+    ebuf, eibuf = orc.precompute_twiddles(half_odds(log), log)
+    assert (host(tw, 1 << log) == ebuf).all() and (host(itw, 1 << log) == eibuf).all()
+    for e in golden["twiddles"]:
+        if e["log"] == log:
+            assert hashlib.blake2s(host(tw, 1 << log).tobytes()).hexdigest() == e["digest"]
+
+
+def test_twiddles_other_cosets():
+    for init, log in [(OL.orc_odds_initial(6), 6), (12345, 7)]:
+        tw, _ = dev_empty(1 << log), None
+        L.call("tstwo_twiddles_build", init, log, vp(tw), C.c_void_p(0))
+        ebuf, _ = orc.precompute_twiddles(init, log, inverse=False)
+        assert (host(tw, 1 << log) == ebuf).all()
+
+
+# ------------------------------------------------------------------ CFFT
+@pytest.mark.parametrize("n", list(range(1, 17)))
+def test_cfft_vs_oracle(n):
+    n_cols = 3
+    tw_log = max(n - 1, 1)
+    tw, itw = build_twiddles(tw_log)
+    otw, oitw = orc.precompute_twiddles(half_odds(tw_log), tw_log)
+    cols = [rand_column(100 * n + c, 1 << n) for c in range(n_cols)]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_cfft_evaluate", ptrs(d), n_cols, n, half_odds(n - 1), vp(tw), tw_log)
+    evs = [host(x, 1 << n) for x in d]
+    for c in range(n_cols):
+        assert (evs[c] == orc.cfft_evaluate(cols[c], n, half_odds(n - 1), otw, tw_log)).all(), f"evaluate log {n} col {c}"
+    L.call("tstwo_cfft_interpolate", ptrs(d), n_cols, n, half_odds(n - 1), vp(itw), tw_log)
+    for c in range(n_cols):
+        assert (host(d[c], 1 << n) == cols[c]).all(), f"interpolate log {n} col {c}"
+    # interpolate of arbitrary values (not a round trip) against the oracle
+    vals = rand_column(7 * n, 1 << n)
+    dv = [dev(vals)]
+    L.call("tstwo_cfft_interpolate", ptrs(dv), 1, n, half_odds(n - 1), vp(itw), tw_log)
+    assert (host(dv[0], 1 << n) == orc.cfft_interpolate(vals, n, half_odds(n - 1), oitw, tw_log)).all()
+
+
+def test_cfft_golden(golden):
+    for e in golden["cfft"]:
+        n = e["log"]
+        tw_log = max(n - 1, 1)
+        tw, _ = build_twiddles(tw_log)
+        d = [dev(column(e["seed"], 1 << n))]
+        L.call("tstwo_cfft_evaluate", ptrs(d), 1, n, e["half_initial"], vp(tw), tw_log)
+        assert hashlib.blake2s(host(d[0], 1 << n).tobytes()).hexdigest() == e["eval_digest"], n
+
+
+def test_cfft_bigger_tree_and_errors():
+    n = 10
+    tw, itw = build_twiddles(14)
+    otw, _ = orc.precompute_twiddles(half_odds(n - 1), n - 1)
+    col = rand_column(55, 1 << n)
+    d = [dev(col)]
+    L.call("tstwo_cfft_evaluate", ptrs(d), 1, n, half_odds(n - 1), vp(tw), 14)
+    assert (host(d[0], 1 << n) == orc.cfft_evaluate(col, n, half_odds(n - 1), otw, n - 1)).all()
+    small, _ = build_twiddles(3)
+    with pytest.raises(L.TstwoError, match="Not enough twiddles"):
+        L.call("tstwo_cfft_evaluate", ptrs(d), 1, n, half_odds(n - 1), vp(small), 3)
+
+
+@pytest.mark.parametrize("n", [18, 20, 22])
+def test_cfft_large_properties(n):
+    """BASELINE sizes: round trip, agreement with eval_at_point at sampled domain points (the reference's
+    property test), linearity, and oracle equality on one column."""
+    tw, itw = build_twiddles(n - 1)
+    a, b = rand_column(n, 1 << n), rand_column(n + 1, 1 << n)
+    s = orc.col_op("add", a, b)
+    d = [dev(a), dev(b), dev(s)]
+    L.call("tstwo_cfft_evaluate", ptrs(d), 3, n, half_odds(n - 1), vp(tw), n - 1)
+    ea, eb, es = (host(x, 1 << n) for x in d)
+    assert (orc.col_op("add", ea, eb) == es).all()                     # linearity
+    rng = np.random.default_rng(n)
+    for i in rng.integers(0, 1 << n, size=6):
+        p = OL.orc_circle_domain_at(half_odds(n - 1), n - 1, int(i))
+        v = orc.eval_at_point(a, n, (p.x, 0, 0, 0), (p.y, 0, 0, 0))
+        assert v == (int(ea[OL.orc_bit_reverse_index(int(i), n)]), 0, 0, 0)
+    if n <= 20:
+        otw, _ = orc.precompute_twiddles(half_odds(n - 1), n - 1, inverse=False)
+        assert (ea == orc.cfft_evaluate(a, n, half_odds(n - 1), otw, n - 1)).all()
+    L.call("tstwo_cfft_interpolate", ptrs(d), 3, n, half_odds(n - 1), vp(itw), n - 1)
+    assert (host(d[0], 1 << n) == a).all() and (host(d[1], 1 << n) == b).all()
+
+
+def test_poly_extend_and_eval_at_point(golden):
+    for e in golden["eval_at_point"]:
+        coeffs = column(e["seed"], 1 << e["log"])
+        d = dev(coeffs)
+        out = (C.c_uint32 * 4)()
+        L.call("tstwo_eval_at_point", vp(d), e["log"], L.u32x(e["point"][0]), L.u32x(e["point"][1]), out)
+        assert list(out) == e["value"], e["log"]
+    for n in (7, 12, 17):
+        coeffs = rand_column(n, 1 << n)
+        d = dev(coeffs)
+        px, py = golden["eval_at_point"][0]["point"]
+        out = (C.c_uint32 * 4)()
+        L.call("tstwo_eval_at_point", vp(d), n, L.u32x(px), L.u32x(py), out)
+        assert tuple(out) == orc.eval_at_point(coeffs, n, px, py)
+    src = rand_column(9, 1 << 5)
+    ds, dd = dev(src), dev_empty(1 << 9)
+    L.call("tstwo_poly_extend", vp(ds), 5, vp(dd), 9)
+    got = host(dd, 1 << 9)
+    assert (got[:32] == src).all() and not got[32:].any()
+    with pytest.raises(L.TstwoError, match="log size too small"):
+        L.call("tstwo_poly_extend", vp(dd), 9, vp(ds), 5)
+
+
+# ------------------------------------------------------------------ FRI
+ALPHA = (19283, 1, 2, 3)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 9, 14])
+def test_fold_line(k):
+    n = 1 << k
+    cols = [rand_column(200 + 4 * k + j, n) for j in range(4)]
+    _, itw = build_twiddles(max(k, 1) + 2)     # tree of half_odds(k+2); line domain = its doubling twice
+    tw_log = max(k, 1) + 2
+    coset_initial = (half_odds(tw_log) << (tw_log - k)) & 0x7FFFFFFF   # root.repeated_double(tw_log-k)
+    d = [dev(c) for c in cols]
+    o = [dev_empty(n // 2) for _ in range(4)]
+    L.call("tstwo_fri_fold_line", p4(d), k, vp(itw), tw_log, L.u32x(ALPHA), p4(o))
+    exp = orc.fold_line(cols, k, coset_initial, ALPHA)
+    for j in range(4):
+        assert (host(o[j], n // 2) == exp[j]).all()
+
+
+def test_fold_line_golden_and_errors(golden):
+    for e in golden["fold_line"]:
+        k = e["log"]
+        cols = [column(s, 1 << k) for s in e["seeds"]]
+        _, itw = build_twiddles(k)              # LineDomain(half_odds(k)) == the tree's root coset
+        d = [dev(c) for c in cols]
+        o = [dev_empty(max((1 << k) // 2, 1)) for _ in range(4)]
+        L.call("tstwo_fri_fold_line", p4(d), k, vp(itw), k, L.u32x(e["alpha"]), p4(o))
+        got = [host(o[j], (1 << k) // 2) for j in range(4)]
+        assert hashlib.blake2s(b"".join(g.tobytes() for g in got)).hexdigest() == e["out_digest"], k
+    d = [dev(np.zeros(1, dtype=np.uint32)) for _ in range(4)]
+    with pytest.raises(L.TstwoError, match="fold_line: Evaluation too small"):
+        L.call("tstwo_fri_fold_line", p4(d), 0, vp(d[0]), 0, L.u32x(ALPHA), p4(d))
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 10, 15])
+def test_fold_circle_into_line(n):
+    N = 1 << n
+    src = [rand_column(300 + 4 * n + j, N) for j in range(4)]
+    dst = [rand_column(400 + 4 * n + j, N // 2) for j in range(4)]
+    _, itw = build_twiddles(n + 1)
+    ds, dd = [dev(c) for c in src], [dev(c) for c in dst]
+    L.call("tstwo_fri_fold_circle_into_line", p4(dd), N // 2, p4(ds), n, vp(itw), n + 1, L.u32x(ALPHA))
+    # domain half coset = root(half_odds(n+1)).repeated_double(2) -> initial index * 4
+    half_initial = (half_odds(n + 1) << 2) & 0x7FFFFFFF
+    exp = orc.fold_circle_into_line(dst, src, n, half_initial, ALPHA)
+    for j in range(4):
+        assert (host(dd[j], N // 2) == exp[j]).all()
+
+
+def test_fold_circle_golden_small_and_errors(golden):
+    for e in golden["fold_circle"]:
+        n = e["log"]
+        src = [column(s, 1 << n) for s in e["src_seeds"]]
+        dst = [column(s, 1 << (n - 1)) for s in e["dst_seeds"]]
+        ds, dd = [dev(c) for c in src], [dev(c) for c in dst]
+        if n >= 3:
+            _, itw = build_twiddles(n - 1)
+            L.call("tstwo_fri_fold_circle_into_line", p4(dd), 1 << (n - 1), p4(ds), n, vp(itw), n - 1, L.u32x(e["alpha"]))
+        else:   # explicit twiddles: y^-1 of domain.at(bitrev(2i, n))
+            inv_y = []
+            for i in range(1 << (n - 1)):
+                p = OL.orc_circle_domain_at(e["half_initial"], n - 1, OL.orc_bit_reverse_index(2 * i, n))
+                inv_y.append(pow(p.y, P - 2, P))
+            dt = dev(np.array(inv_y, dtype=np.uint32))
+            L.call("tstwo_fri_fold_circle_into_line_tw", p4(dd), 1 << (n - 1), p4(ds), n, vp(dt), L.u32x(e["alpha"]))
+        got = [host(dd[j], 1 << (n - 1)) for j in range(4)]
+        assert hashlib.blake2s(b"".join(g.tobytes() for g in got)).hexdigest() == e["out_digest"], n
+    with pytest.raises(L.TstwoError, match="fold_circle_into_line: Length mismatch"):
+        L.call("tstwo_fri_fold_circle_into_line", p4(dd), 3, p4(ds), 4, vp(dd[0]), 4, L.u32x(ALPHA))
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 1000 * 0 + 1024, 1 << 16])
+def test_decompose(n):
+    cols = [rand_column(500 + k, n) for k in range(4)]
+    d, o = [dev(c) for c in cols], [dev_empty(n) for _ in range(4)]
+    lam = (C.c_uint32 * 4)()
+    L.call("tstwo_fri_decompose", p4(d), n, p4(o), lam)
+    exp, elam = orc.decompose(cols)
+    assert tuple(lam) == elam
+    for k in range(4):
+        assert (host(o[k], n) == exp[k]).all()
+
+
+# ------------------------------------------------------------------ Merkle
+def merkle_commit(cols, log_sizes):
+    max_log = max(log_sizes) if cols else 0
+    layers = L.DeviceBuffer(32 * ((2 << max_log) - 1))
+    d = [dev(c) for c in cols]
+    root = (C.c_uint8 * 32)()
+    L.call("tstwo_merkle_commit", ptrs(d), L.u32x(log_sizes), len(cols), vp(layers), root)
+    flat = layers.download(np.uint8).reshape(-1, 32)
+    return [flat[(1 << k) - 1:(2 << k) - 1] for k in range(max_log + 1)], bytes(root)
+
+
+def test_merkle_golden(golden):
+    for e in golden["merkle"]:
+        cols = [column(e["seed_base"] + i, 1 << lg) for i, lg in enumerate(e["log_sizes"])]
+        layers, root = merkle_commit(cols, e["log_sizes"])
+        assert root.hex() == e["root"], e["name"]
+        assert hashlib.blake2s(b"".join(l.tobytes() for l in layers)).hexdigest() == e["layers_digest"], e["name"]
+    e = golden["merkle_lcg"]
+    layers, root = merkle_commit([np.array(c, dtype=np.uint32) for c in e["cols"]], e["log_sizes"])
+    assert root.hex() == e["root"]
+    assert [[bytes(h).hex() for h in l] for l in layers] == e["layers"]
+
+
+@pytest.mark.parametrize("n_cols,log", [(1, 10), (4, 12), (15, 9), (16, 9), (17, 9), (32, 11), (48, 8), (256, 6), (300, 5), (600, 4)])
+def test_merkle_vs_oracle(n_cols, log):
+    cols = [rand_column(600 + c, 1 << log) for c in range(n_cols)]
+    layers, root = merkle_commit(cols, [log] * n_cols)
+    olayers, oroot = orc.merkle_commit(cols, [log] * n_cols)
+    assert root == oroot
+    for a, b in zip(layers, olayers):
+        assert (a == b).all()
+
+
+def test_merkle_commit_layer_with_prev_and_columns():
+    log = 7
+    big = [rand_column(700 + c, 1 << (log + 1)) for c in range(3)]
+    small = [rand_column(710 + c, 1 << log) for c in range(20)]
+    dprev = dev_empty(8 << (log + 1))
+    dbig, dsmall = [dev(c) for c in big], [dev(c) for c in small]
+    L.call("tstwo_merkle_commit_layer", log + 1, C.c_void_p(0), ptrs(dbig), 3, vp(dprev))
+    out = dev_empty(8 << log)
+    L.call("tstwo_merkle_commit_layer", log, vp(dprev), ptrs(dsmall), 20, vp(out))
+    prev = orc.commit_on_layer(log + 1, None, big)
+    assert (host(dprev, 32 << (log + 1), np.uint8).reshape(-1, 32) == prev).all()
+    assert (host(out, 32 << log, np.uint8).reshape(-1, 32) == orc.commit_on_layer(log, prev, small)).all()
+
+
+def test_merkle_large_property():
+    """log 20, 4 columns: root equals the oracle's, and a checksum of all layers matches."""
+    log = 20
+    cols = [rand_column(800 + c, 1 << log) for c in range(4)]
+    layers, root = merkle_commit(cols, [log] * 4)
+    olayers, oroot = orc.merkle_commit(cols, [log] * 4)
+    assert root == oroot
+    assert hashlib.blake2s(b"".join(l.tobytes() for l in layers)).digest() == hashlib.blake2s(b"".join(l.tobytes() for l in olayers)).digest()
+
+
+# ------------------------------------------------------------------ quotients
+def gpu_quotients(half_initial, log, cols, random_coeff, batches):
+    """batches: [(px, py, [(col, value4)])] in Rust semantics; constants come from the oracle's line-coeff helper."""
+    off, cidx, abc, bcoef, prx, pry, pix, piy = [0], [], [], [], [], [], [], []
+    for px, py, cv in batches:
+        alpha = (1, 0, 0, 0)
+        for ci, v in cv:
+            alpha = OL.orc_qm31_mul(orc.q(alpha), orc.q(random_coeff)).tup()
+            out = (orc.QM31 * 3)()
+            OL.orc_line_coeffs(orc.SPoint(orc.q(px), orc.q(py)), orc.q(v), orc.q(alpha), out)
+            for t in out:
+                abc += list(t.tup())
+            cidx.append(ci)
+        off.append(len(cidx))
+        bcoef += list(alpha)
+        prx += px[:2]; pry += py[:2]; pix += px[2:]; piy += py[2:]
+    d = [dev(c) for c in cols]
+    o = [dev_empty(1 << log) for _ in range(4)]
+    L.call("tstwo_quotients_accumulate", half_initial, log, ptrs(d), len(cols), len(batches), L.u32x(off), L.u32x(cidx),
+           L.u32x(abc), L.u32x(bcoef), L.u32x(prx), L.u32x(pry), L.u32x(pix), L.u32x(piy), p4(o))
+    return [host(x, 1 << log) for x in o]
+
+
+def test_quotients_golden(golden):
+    e = golden["quotients"][1]
+    n = e["log"]
+    cols = [column(s, 1 << n) for s in e["col_seeds"]]
+    batches = [(b["point"][0], b["point"][1], [(ci, v) for ci, v in b["cols"]]) for b in e["batches"]]
+    got = gpu_quotients(e["half_initial"], n, cols, e["random_coeff"], batches)
+    assert hashlib.blake2s(b"".join(g.tobytes() for g in got)).hexdigest() == e["out_digest"]
+    e0 = golden["quotients"][0]
+    n = e0["log"]
+    coeffs = column(e0["coeffs_seed"], 1 << e0["poly_log"])
+    ext = np.concatenate([coeffs, np.zeros((1 << n) - coeffs.size, dtype=np.uint32)])
+    otw, _ = orc.precompute_twiddles(half_odds(n - 1), n - 1, inverse=False)
+    ev = orc.cfft_evaluate(ext, n, e0["half_initial"], otw, n - 1)
+    got = gpu_quotients(e0["half_initial"], n, [ev], e0["random_coeff"], [(e0["point"][0], e0["point"][1], [(0, e0["value"])])])
+    assert [g.tolist() for g in got] == e0["out"]
+
+
+@pytest.mark.parametrize("log", [1, 2, 3, 6, 12, 16])
+def test_quotients_vs_oracle(log, golden):
+    px, py = golden["eval_at_point"][0]["point"]
+    n_cols = 5
+    cols = [rand_column(900 + log * 8 + c, 1 << log) for c in range(n_cols)]
+    vals = [tuple(int(x) for x in rand_column(950 + j, 4)) for j in range(6)]
+    py2 = OL.orc_qm31_mul(orc.q(py), orc.q(py)).tup()
+    batches = [(px, py, [(0, vals[0]), (3, vals[1]), (4, vals[2])]), (py, py2, [(1, vals[3])]), (px, py2, [(2, vals[4]), (0, vals[5])])]
+    got = gpu_quotients(half_odds(log - 1), log, cols, (1, 2, 3, 4), batches)
+    exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (1, 2, 3, 4), batches)
+    for k in range(4):
+        assert (got[k] == exp[k]).all()

@@ -1,0 +1,226 @@
+"""ctypes binding of libtstwo_hip.so — the same C ABI (include/tstwo_hip.h) a bun:ffi HipBackend binds.
+
+There is NO CPU fallback: loading fails loudly if the shared library is missing, and every entry
+point returns an error if no GPU is present.  Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtstwo_hip.so")
+P = 2147483647
+
+
+class TstwoError(RuntimeError):
+    """Raised with the reference's own error text (e.g. "0 has no inverse")."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+P4 = vp * 4
+P2 = vp * 2
+
+_SIGS = {
+    "tstwo_init": [C.c_int],
+    "tstwo_shutdown": [],
+    "tstwo_device_count": [C.POINTER(C.c_int)],
+    "tstwo_device_name": [C.c_char_p, C.c_size_t],
+    "tstwo_set_stream": [vp],
+    "tstwo_sync": [],
+    "tstwo_malloc": [C.POINTER(vp), C.c_size_t],
+    "tstwo_free": [vp],
+    "tstwo_upload": [vp, vp, C.c_size_t],
+    "tstwo_download": [vp, vp, C.c_size_t],
+    "tstwo_copy": [vp, vp, C.c_size_t],
+    "tstwo_zero": [vp, C.c_size_t],
+    "tstwo_event_create": [C.POINTER(vp)],
+    "tstwo_event_record": [vp],
+    "tstwo_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+    "tstwo_event_destroy": [vp],
+    "tstwo_m31_add": [vp, vp, vp, C.c_size_t],
+    "tstwo_m31_sub": [vp, vp, vp, C.c_size_t],
+    "tstwo_m31_mul": [vp, vp, vp, C.c_size_t],
+    "tstwo_m31_neg": [vp, vp, C.c_size_t],
+    "tstwo_m31_batch_inverse": [vp, vp, C.c_size_t],
+    "tstwo_cm31_batch_inverse": [P2, P2, C.c_size_t],
+    "tstwo_qm31_batch_inverse": [P4, P4, C.c_size_t],
+    "tstwo_qm31_mul": [P4, P4, P4, C.c_size_t],
+    "tstwo_secure_accumulate": [P4, P4, C.c_size_t],
+    "tstwo_bit_reverse": [C.POINTER(vp), C.c_size_t, C.c_size_t],
+    "tstwo_twiddles_build": [C.c_uint32, C.c_uint32, vp, vp],
+    "tstwo_cfft_evaluate": [C.POINTER(vp), C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_uint32],
+    "tstwo_cfft_interpolate": [C.POINTER(vp), C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_uint32],
+    "tstwo_poly_extend": [vp, C.c_uint32, vp, C.c_uint32],
+    "tstwo_eval_at_point": [vp, C.c_uint32, u32p, u32p, u32p],
+    "tstwo_fri_fold_line": [P4, C.c_uint32, vp, C.c_uint32, u32p, P4],
+    "tstwo_fri_fold_circle_into_line": [P4, C.c_size_t, P4, C.c_uint32, vp, C.c_uint32, u32p],
+    "tstwo_fri_fold_line_tw": [P4, C.c_uint32, vp, u32p, P4],
+    "tstwo_fri_fold_circle_into_line_tw": [P4, C.c_size_t, P4, C.c_uint32, vp, u32p],
+    "tstwo_fri_decompose": [P4, C.c_size_t, P4, u32p],
+    "tstwo_merkle_commit_layer": [C.c_uint32, vp, C.POINTER(vp), C.c_size_t, vp],
+    "tstwo_merkle_commit": [C.POINTER(vp), u32p, C.c_size_t, vp, u8p],
+    "tstwo_quotients_accumulate": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,
+                                   u32p, u32p, u32p, u32p, u32p, P4],
+}
+# every symbol include/tstwo_hip.h declares (tests check the library exports all of them)
+EXPORTS = sorted(list(_SIGS) + ["tstwo_last_error", "tstwo_version", "tstwo_merkle_layers_bytes"])
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """dlopen the in-tree HIP library.  Raises if it was not built (python -m tstwo_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TstwoError(-1, f"{LIB_PATH} is missing: build it with `python -m tstwo_amd.build` "
+                                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = args
+        L.tstwo_last_error.restype = C.c_char_p
+        L.tstwo_last_error.argtypes = []
+        L.tstwo_version.restype = C.c_char_p
+        L.tstwo_version.argtypes = []
+        L.tstwo_merkle_layers_bytes.restype = C.c_size_t
+        L.tstwo_merkle_layers_bytes.argtypes = [C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc:
+        raise TstwoError(rc, lib().tstwo_last_error().decode("utf-8", "replace"))
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args))
+
+
+_initialised = False
+
+
+def init(device: int | None = None) -> None:
+    """Select the GPU (LOCAL_RANK by default, one process per GPU) and create the stream."""
+    global _initialised
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        n = device_count()
+        if n:
+            device %= n
+    call("tstwo_init", device)
+    _initialised = True
+
+
+def ensure_init() -> None:
+    if not _initialised:
+        init()
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().tstwo_device_count(C.byref(n))
+    return n.value
+
+
+def device_name() -> str:
+    ensure_init()
+    buf = C.create_string_buffer(256)
+    call("tstwo_device_name", buf, 256)
+    return buf.value.decode()
+
+
+def sync() -> None:
+    ensure_init()
+    call("tstwo_sync")
+
+
+class DeviceBuffer:
+    """An owned device allocation (tstwo_malloc / tstwo_free)."""
+
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, nbytes: int):
+        ensure_init()
+        p = vp()
+        call("tstwo_malloc", C.byref(p), nbytes)
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def free(self) -> None:
+        if self.ptr:
+            call("tstwo_free", vp(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.tstwo_free(vp(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+    # -- host transfer
+    def upload(self, arr: np.ndarray, offset: int = 0) -> None:
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        call("tstwo_upload", vp(self.ptr + offset), arr.ctypes.data_as(vp), arr.nbytes)
+
+    def download(self, dtype=np.uint32, count: int | None = None, offset: int = 0) -> np.ndarray:
+        dt = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset) // dt.itemsize
+        out = np.empty(count, dtype=dt)
+        call("tstwo_download", out.ctypes.data_as(vp), vp(self.ptr + offset), out.nbytes)
+        return out
+
+    def zero(self) -> None:
+        call("tstwo_zero", vp(self.ptr), self.nbytes)
+
+
+def ptr_array(ptrs) -> C.Array:
+    ptrs = list(ptrs)
+    return (vp * max(len(ptrs), 1))(*ptrs)
+
+
+def p4(ptrs):
+    return P4(*ptrs)
+
+
+def u32x(vals):
+    return (C.c_uint32 * max(len(vals), 1))(*[int(v) for v in vals])
+
+
+class Event:
+    def __init__(self):
+        ensure_init()
+        e = vp()
+        call("tstwo_event_create", C.byref(e))
+        self.h = e
+
+    def record(self):
+        call("tstwo_event_record", self.h)
+        return self
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        call("tstwo_event_elapsed_ms", self.h, stop.h, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if _lib is not None and self.h:
+                _lib.tstwo_event_destroy(self.h)
+        except Exception:
+            pass

@@ -1,0 +1,58 @@
+// common.h — shared host-side plumbing of libtstwo_hip.so (context, error text, launch helpers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/tstwo_hip.h"
+#include "m31.cuh"
+
+namespace tstwo {
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;     // stream every launch goes to (own_stream or a borrowed one)
+    cpoint *gen_pow2 = nullptr;       // device: GEN * 2^k, k = 0..30 (circle.ts:137)
+    u32 *flag = nullptr;              // device: error flag word (zero-inverse detection)
+    u32 *scratch = nullptr;           // device scratch for reductions (decompose / eval_at_point)
+    size_t scratch_bytes = 0;
+    int n_cus = 256;
+};
+
+Context &ctx();
+int set_error(int code, const char *msg);
+int set_error(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+int require_ready();
+int ensure_scratch(size_t bytes);
+// reads the device error flag (synchronises the stream) and clears it
+int read_and_clear_flag(u32 *value);
+
+#define TSTWO_HIP(call)                                        \
+    do {                                                       \
+        hipError_t _e = (call);                                \
+        if (_e != hipSuccess) return ::tstwo::hip_fail(_e, #call); \
+    } while (0)
+
+#define TSTWO_REQUIRE_READY()                      \
+    do {                                           \
+        int _rc = ::tstwo::require_ready();        \
+        if (_rc) return _rc;                       \
+    } while (0)
+
+#define TSTWO_LAUNCH_CHECK() TSTWO_HIP(hipGetLastError())
+
+static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// by-value pointer tables passed as kernel arguments (no device-side pointer arrays to manage)
+constexpr int kMaxColsPerLaunch = 64;    // CFFT / bit-reverse batch chunk
+struct ColPtrs { u32 *p[kMaxColsPerLaunch]; };
+constexpr int kMaxHashCols = 256;        // Merkle: columns absorbed per launch (multiple of 16)
+struct HashColPtrs { const u32 *p[kMaxHashCols]; };
+struct Soa4 { u32 *p[4]; };
+struct CSoa4 { const u32 *p[4]; };
+
+}  // namespace tstwo

@@ -1,0 +1,218 @@
+// context.hip — lifecycle, device memory, stream and event plumbing of the C ABI (include/tstwo_hip.h).
+#include "common.h"
+
+#include <string.h>
+
+namespace tstwo {
+
+static Context g_ctx;
+static thread_local std::string g_last_error;
+
+Context &ctx() { return g_ctx; }
+
+int set_error(int code, const char *msg) {
+    g_last_error = msg ? msg : "";
+    return code;
+}
+int set_error(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    (void)hipGetLastError();
+    return TSTWO_ERR_HIP;
+}
+int require_ready() {
+    if (!g_ctx.ready) {
+        int rc = tstwo_init(0);
+        if (rc) return rc;
+    }
+    return TSTWO_OK;
+}
+int ensure_scratch(size_t bytes) {
+    Context &c = g_ctx;
+    if (c.scratch_bytes >= bytes) return TSTWO_OK;
+    if (c.scratch) {
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        TSTWO_HIP(hipFree(c.scratch));
+        c.scratch = nullptr;
+        c.scratch_bytes = 0;
+    }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    TSTWO_HIP(hipMalloc((void **)&c.scratch, want));
+    c.scratch_bytes = want;
+    return TSTWO_OK;
+}
+int read_and_clear_flag(u32 *value) {
+    Context &c = g_ctx;
+    TSTWO_HIP(hipMemcpyAsync(value, c.flag, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    if (*value) TSTWO_HIP(hipMemsetAsync(c.flag, 0, sizeof(u32), c.stream));
+    return TSTWO_OK;
+}
+
+// host-side M31 helpers for the one-time generator table (circle.ts:101-105,137)
+static u32 h_mul(u32 a, u32 b) {
+    u64 p = (u64)a * b;
+    u64 s = (p & M31_P) + (p >> 31);
+    s = (s & M31_P) + (s >> 31);
+    return s >= M31_P ? (u32)(s - M31_P) : (u32)s;
+}
+static u32 h_add(u32 a, u32 b) { u32 s = a + b; return s >= M31_P ? s - M31_P : s; }
+static u32 h_sub(u32 a, u32 b) { return a >= b ? a - b : a + M31_P - b; }
+
+}  // namespace tstwo
+
+using namespace tstwo;
+
+extern "C" {
+
+const char *tstwo_last_error(void) { return g_last_error.c_str(); }
+const char *tstwo_version(void) { return "tstwo_hip 0.1 (gfx950)"; }
+
+int tstwo_device_count(int *out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    if (out) *out = n;
+    return TSTWO_OK;
+}
+
+int tstwo_init(int device) {
+    Context &c = g_ctx;
+    if (c.ready && c.device == device) return TSTWO_OK;
+    if (c.ready) tstwo_shutdown();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        return set_error(TSTWO_ERR_HIP, "no HIP device available: libtstwo_hip has no CPU fallback");
+    }
+    if (device < 0 || device >= n) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_init: device index out of range");
+    TSTWO_HIP(hipSetDevice(device));
+    TSTWO_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    c.device = device;
+    hipDeviceProp_t prop;
+    TSTWO_HIP(hipGetDeviceProperties(&prop, device));
+    c.n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // GEN * 2^k table
+    cpoint tab[31];
+    cpoint g = {2u, 1268011823u};
+    for (int k = 0; k < 31; k++) {
+        tab[k] = g;
+        cpoint d = {h_sub(h_mul(g.x, g.x), h_mul(g.y, g.y)), h_add(h_mul(g.x, g.y), h_mul(g.y, g.x))};
+        g = d;
+    }
+    TSTWO_HIP(hipMalloc((void **)&c.gen_pow2, sizeof(tab)));
+    TSTWO_HIP(hipMemcpy(c.gen_pow2, tab, sizeof(tab), hipMemcpyHostToDevice));
+    TSTWO_HIP(hipMalloc((void **)&c.flag, 64));
+    TSTWO_HIP(hipMemset(c.flag, 0, 64));
+    c.ready = true;
+    return TSTWO_OK;
+}
+
+int tstwo_shutdown(void) {
+    Context &c = g_ctx;
+    if (!c.ready) return TSTWO_OK;
+    (void)hipStreamSynchronize(c.stream);
+    if (c.gen_pow2) (void)hipFree(c.gen_pow2);
+    if (c.flag) (void)hipFree(c.flag);
+    if (c.scratch) (void)hipFree(c.scratch);
+    if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+    c = Context();
+    return TSTWO_OK;
+}
+
+int tstwo_device_name(char *buf, size_t buflen) {
+    TSTWO_REQUIRE_READY();
+    hipDeviceProp_t prop;
+    TSTWO_HIP(hipGetDeviceProperties(&prop, g_ctx.device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return TSTWO_OK;
+}
+
+int tstwo_set_stream(void *hip_stream) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    g_ctx.stream = hip_stream ? (hipStream_t)hip_stream : g_ctx.own_stream;
+    return TSTWO_OK;
+}
+
+int tstwo_sync(void) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    return TSTWO_OK;
+}
+
+int tstwo_malloc(void **dev, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (!dev) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_malloc: null out pointer");
+    *dev = nullptr;
+    if (bytes == 0) bytes = 16;
+    TSTWO_HIP(hipMalloc(dev, bytes));
+    return TSTWO_OK;
+}
+int tstwo_free(void *dev) {
+    if (!dev) return TSTWO_OK;
+    TSTWO_REQUIRE_READY();
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    TSTWO_HIP(hipFree(dev));
+    return TSTWO_OK;
+}
+int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (bytes == 0) return TSTWO_OK;
+    TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    return TSTWO_OK;
+}
+int tstwo_download(void *host_dst, const void *dev_src, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (bytes == 0) return TSTWO_OK;
+    TSTWO_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    return TSTWO_OK;
+}
+int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (bytes == 0) return TSTWO_OK;
+    TSTWO_HIP(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, g_ctx.stream));
+    return TSTWO_OK;
+}
+int tstwo_zero(void *dev, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (bytes == 0) return TSTWO_OK;
+    TSTWO_HIP(hipMemsetAsync(dev, 0, bytes, g_ctx.stream));
+    return TSTWO_OK;
+}
+
+int tstwo_event_create(void **ev) {
+    TSTWO_REQUIRE_READY();
+    hipEvent_t e;
+    TSTWO_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return TSTWO_OK;
+}
+int tstwo_event_record(void *ev) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_HIP(hipEventRecord((hipEvent_t)ev, g_ctx.stream));
+    return TSTWO_OK;
+}
+int tstwo_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+    TSTWO_HIP(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return TSTWO_OK;
+}
+int tstwo_event_destroy(void *ev) {
+    if (!ev) return TSTWO_OK;
+    TSTWO_HIP(hipEventDestroy((hipEvent_t)ev));
+    return TSTWO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// field_ops.hip — column arithmetic, batch inversion, bit-reversal and twiddle-tree generation.
+//
+// All of these are HBM-streaming kernels: one coalesced 16-byte access per lane where alignment
+// allows, grid capped at a few waves per SIMD and grid-strided (guide §6 G11/G13).  Algorithmic
+// bytes per element: add/sub/mul 12 B, neg 8 B, m31 batch inverse 8 B,
+// qm31 batch inverse 32 B, bit reverse 8 B.
+#include "common.h"
+
+using namespace tstwo;
+
+namespace {
+
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_NEG = 3 };
+
+template <int OP>
+__device__ __forceinline__ u32 apply_op(u32 a, u32 b) {
+    if (OP == OP_ADD) return m31_add(a, b);
+    if (OP == OP_SUB) return m31_sub(a, b);
+    if (OP == OP_MUL) return m31_mul(a, b);
+    return m31_neg(a);
+}
+
+// fields/m31.ts:147-173 applied per element; 4 elements (16 B) per lane per iteration
+template <int OP>
+__global__ void __launch_bounds__(256) k_m31_binop_vec4(const uint4 *__restrict__ a, const uint4 *__restrict__ b,
+                                                        uint4 *__restrict__ out, size_t n4) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        uint4 x = a[i];
+        uint4 y = (OP == OP_NEG) ? x : b[i];
+        uint4 r;
+        r.x = apply_op<OP>(x.x, y.x);
+        r.y = apply_op<OP>(x.y, y.y);
+        r.z = apply_op<OP>(x.z, y.z);
+        r.w = apply_op<OP>(x.w, y.w);
+        out[i] = r;
+    }
+}
+template <int OP>
+__global__ void __launch_bounds__(256) k_m31_binop_scalar(const u32 *__restrict__ a, const u32 *__restrict__ b,
+                                                          u32 *__restrict__ out, size_t begin, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = apply_op<OP>(a[i], (OP == OP_NEG) ? 0u : b[i]);
+}
+
+template <int OP>
+int launch_binop(const u32 *a, const u32 *b, u32 *out, size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return TSTWO_OK;
+    if (!a || !out || (OP != OP_NEG && !b)) return set_error(TSTWO_ERR_BAD_ARG, "null column pointer");
+    Context &c = ctx();
+    bool aligned = (((uintptr_t)a | (uintptr_t)out | (uintptr_t)(OP == OP_NEG ? a : b)) & 15) == 0;
+    size_t n4 = aligned ? n / 4 : 0;
+    unsigned max_blocks = (unsigned)c.n_cus * 8;
+    if (n4) {
+        unsigned blocks = ceil_div(n4, 256);
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL(k_m31_binop_vec4<OP>, dim3(blocks), dim3(256), 0, c.stream, (const uint4 *)a,
+                           (const uint4 *)b, (uint4 *)out, n4);
+    }
+    if (n4 * 4 < n) {
+        size_t rest = n - n4 * 4;
+        unsigned blocks = ceil_div(rest, 256);
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL(k_m31_binop_scalar<OP>, dim3(blocks), dim3(256), 0, c.stream, a, b, out, n4 * 4, n);
+    }
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+// ---------------------------------------------------------------- QM31 SoA elementwise
+__global__ void __launch_bounds__(256) k_qm31_mul(CSoa4 a, CSoa4 b, Soa4 o, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        qm31 x = {a.p[0][i], a.p[1][i], a.p[2][i], a.p[3][i]};
+        qm31 y = {b.p[0][i], b.p[1][i], b.p[2][i], b.p[3][i]};
+        qm31 r = qm31_mul(x, y);
+        o.p[0][i] = r.a; o.p[1][i] = r.b; o.p[2][i] = r.c; o.p[3][i] = r.d;
+    }
+}
+// backend/cpu/accumulation.ts:38-49: col[k][i] += other[k][i]
+__global__ void __launch_bounds__(256) k_secure_accumulate(Soa4 col, CSoa4 other, size_t n) {
+    u32 *c = col.p[blockIdx.y];
+    const u32 *o = other.p[blockIdx.y];
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c[i] = m31_add(c[i], o[i]);
+}
+
+// ---------------------------------------------------------------- batch inverse
+// Montgomery's trick per thread over K elements strided by the thread count (coalesced for every j),
+// one Fermat chain (fields/m31.ts:305-326) per thread: 3(K-1)+37 multiplications per K elements.
+// The result is the unique elementwise inverse, i.e. what fields/fields.ts:66-207 returns.
+// A zero input raises the flag (the reference throws "0 has no inverse") and is treated as 1.
+template <int K>
+__global__ void __launch_bounds__(256) k_m31_batch_inverse(const u32 *__restrict__ in, u32 *__restrict__ out, size_t n,
+                                                          size_t T, u32 *flag) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    u32 x[K], pre[K];
+    bool zero = false;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        size_t i = t + (size_t)j * T;
+        u32 v = i < n ? in[i] : 1u;
+        if (v == 0) { zero = true; v = 1u; }
+        x[j] = v;
+        pre[j] = j == 0 ? v : m31_mul(pre[j - 1], v);
+    }
+    if (zero) atomicOr(flag, 1u);
+    u32 cur = m31_inv(pre[K - 1]);
+#pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        size_t i = t + (size_t)j * T;
+        u32 r = j == 0 ? cur : m31_mul(pre[j - 1], cur);
+        cur = m31_mul(cur, x[j]);
+        if (i < n) out[i] = r;
+    }
+}
+
+struct CSoa2 { const u32 *p[2]; };
+struct Soa2 { u32 *p[2]; };
+template <int K>
+__global__ void __launch_bounds__(256) k_cm31_batch_inverse(CSoa2 in, Soa2 out, size_t n, size_t T, u32 *flag) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    cm31 x[K], pre[K];
+    bool zero = false;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        size_t i = t + (size_t)j * T;
+        cm31 v = {1u, 0u};
+        if (i < n) v = {in.p[0][i], in.p[1][i]};
+        if (cm31_is_zero(v)) { zero = true; v = {1u, 0u}; }
+        x[j] = v;
+        pre[j] = j == 0 ? v : cm31_mul(pre[j - 1], v);
+    }
+    if (zero) atomicOr(flag, 1u);
+    cm31 cur = cm31_inv(pre[K - 1]);
+#pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        size_t i = t + (size_t)j * T;
+        cm31 r = j == 0 ? cur : cm31_mul(pre[j - 1], cur);
+        cur = cm31_mul(cur, x[j]);
+        if (i < n) { out.p[0][i] = r.a; out.p[1][i] = r.b; }
+    }
+}
+template <int K>
+__global__ void __launch_bounds__(256) k_qm31_batch_inverse(CSoa4 in, Soa4 out, size_t n, size_t T, u32 *flag) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    qm31 x[K], pre[K];
+    bool zero = false;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        size_t i = t + (size_t)j * T;
+        qm31 v = {1u, 0u, 0u, 0u};
+        if (i < n) v = {in.p[0][i], in.p[1][i], in.p[2][i], in.p[3][i]};
+        if (qm31_is_zero(v)) { zero = true; v = {1u, 0u, 0u, 0u}; }
+        x[j] = v;
+        pre[j] = j == 0 ? v : qm31_mul(pre[j - 1], v);
+    }
+    if (zero) atomicOr(flag, 1u);
+    qm31 cur = qm31_inv(pre[K - 1]);
+#pragma unroll
+    for (int j = K - 1; j >= 0; j--) {
+        size_t i = t + (size_t)j * T;
+        qm31 r = j == 0 ? cur : qm31_mul(pre[j - 1], cur);
+        cur = qm31_mul(cur, x[j]);
+        if (i < n) { out.p[0][i] = r.a; out.p[1][i] = r.b; out.p[2][i] = r.c; out.p[3][i] = r.d; }
+    }
+}
+
+int finish_inverse() {
+    u32 flag = 0;
+    int rc = read_and_clear_flag(&flag);
+    if (rc) return rc;
+    if (flag) return set_error(TSTWO_ERR_ZERO_INVERSE, "0 has no inverse");
+    return TSTWO_OK;
+}
+
+// ---------------------------------------------------------------- bit reverse (backend/cpu/index.ts:62-79)
+// In-place swap of i <-> bitrev(i) for i < bitrev(i); one column per blockIdx.y.
+__global__ void __launch_bounds__(256) k_bit_reverse(ColPtrs cols, u32 log_n) {
+    u32 *v = cols.p[blockIdx.y];
+    size_t n = (size_t)1 << log_n;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        u32 j = __brev((u32)i) >> (32 - log_n);
+        if (j > i) {
+            u32 a = v[i], b = v[j];
+            v[i] = b;
+            v[j] = a;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- twiddle tree (backend/cpu/circle.ts:210-221)
+// Entry e of the tree of coset (init, m): level lvl holds the x coordinates of the first half of
+// coset.repeated_double(lvl), bit-reversed; the last entry is 1.
+__global__ void __launch_bounds__(256) k_twiddles(u32 init, u32 m, u32 *__restrict__ tw, const cpoint *__restrict__ gen_pow2) {
+    size_t total = (size_t)1 << m;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    if (e == total - 1) { tw[e] = 1u; return; }
+    u32 r = (u32)(total - e);                    // 2 <= r <= 2^m
+    u32 lg = 32 - __clz(r - 1);                  // ceil(log2 r) = log size of this level's coset
+    u32 lvl = m - lg;
+    u32 off = (u32)(total - ((size_t)1 << lg));
+    u32 j = (u32)e - off;                        // < 2^(lg-1)
+    u32 k = lg > 1 ? (__brev(j) >> (32 - (lg - 1))) : 0u;
+    u32 init_l = (init << lvl) & 0x7fffffffu;    // Coset.double(): initial*2, circle.ts:253-256
+    u32 idx = (init_l + (k << (31 - lg))) & 0x7fffffffu;
+    tw[e] = cpoint_from_index(idx, gen_pow2).x;
+}
+
+__global__ void __launch_bounds__(256) k_extend(const u32 *__restrict__ src, size_t n_src, u32 *__restrict__ dst, size_t n_dst) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += stride) dst[i] = i < n_src ? src[i] : 0u;
+}
+
+unsigned capped_blocks(size_t work_items, unsigned threads) {
+    unsigned blocks = ceil_div(work_items, threads);
+    unsigned cap = (unsigned)ctx().n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    return blocks ? blocks : 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tstwo_m31_add(const u32 *a, const u32 *b, u32 *out, size_t n) { return launch_binop<OP_ADD>(a, b, out, n); }
+int tstwo_m31_sub(const u32 *a, const u32 *b, u32 *out, size_t n) { return launch_binop<OP_SUB>(a, b, out, n); }
+int tstwo_m31_mul(const u32 *a, const u32 *b, u32 *out, size_t n) { return launch_binop<OP_MUL>(a, b, out, n); }
+int tstwo_m31_neg(const u32 *a, u32 *out, size_t n) { return launch_binop<OP_NEG>(a, nullptr, out, n); }
+
+int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return TSTWO_OK;
+    constexpr int K = 16;
+    size_t T = (n + K - 1) / K;
+    hipLaunchKernelGGL(k_m31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, in, out, n, T, ctx().flag);
+    TSTWO_LAUNCH_CHECK();
+    return finish_inverse();
+}
+int tstwo_cm31_batch_inverse(const u32 *const in[2], u32 *const out[2], size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return TSTWO_OK;
+    constexpr int K = 8;
+    size_t T = (n + K - 1) / K;
+    CSoa2 i2 = {{in[0], in[1]}};
+    Soa2 o2 = {{out[0], out[1]}};
+    hipLaunchKernelGGL(k_cm31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i2, o2, n, T, ctx().flag);
+    TSTWO_LAUNCH_CHECK();
+    return finish_inverse();
+}
+int tstwo_qm31_batch_inverse(const u32 *const in[4], u32 *const out[4], size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return TSTWO_OK;
+    constexpr int K = 8;
+    size_t T = (n + K - 1) / K;
+    CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    hipLaunchKernelGGL(k_qm31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i4, o4, n, T, ctx().flag);
+    TSTWO_LAUNCH_CHECK();
+    return finish_inverse();
+}
+
+int tstwo_qm31_mul(const u32 *const a[4], const u32 *const b[4], u32 *const out[4], size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return TSTWO_OK;
+    CSoa4 a4 = {{a[0], a[1], a[2], a[3]}}, b4 = {{b[0], b[1], b[2], b[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    hipLaunchKernelGGL(k_qm31_mul, dim3(capped_blocks(n, 256)), dim3(256), 0, ctx().stream, a4, b4, o4, n);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_secure_accumulate(u32 *const col[4], const u32 *const other[4], size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return TSTWO_OK;
+    Soa4 c4 = {{col[0], col[1], col[2], col[3]}};
+    CSoa4 o4 = {{other[0], other[1], other[2], other[3]}};
+    hipLaunchKernelGGL(k_secure_accumulate, dim3(capped_blocks(n, 256), 4), dim3(256), 0, ctx().stream, c4, o4, n);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_bit_reverse(u32 *const *cols, size_t n_cols, size_t n) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0 || (n & (n - 1)) != 0) return set_error(TSTWO_ERR_NOT_POW2, "length is not power of two");
+    u32 log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    if (log_n == 0 || n_cols == 0) return TSTWO_OK;
+    for (size_t base = 0; base < n_cols; base += kMaxColsPerLaunch) {
+        size_t cnt = n_cols - base < (size_t)kMaxColsPerLaunch ? n_cols - base : (size_t)kMaxColsPerLaunch;
+        ColPtrs cp;
+        for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[base + i];
+        unsigned blocks = capped_blocks(n, 256);
+        hipLaunchKernelGGL(k_bit_reverse, dim3(blocks, (unsigned)cnt), dim3(256), 0, ctx().stream, cp, log_n);
+    }
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_twiddles_build(u32 coset_initial, u32 log_size, u32 *tw, u32 *itw) {
+    TSTWO_REQUIRE_READY();
+    if (log_size > 30 || !tw) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_twiddles_build: bad log_size or null buffer");
+    size_t n = (size_t)1 << log_size;
+    hipLaunchKernelGGL(k_twiddles, dim3(ceil_div(n, 256)), dim3(256), 0, ctx().stream, coset_initial & 0x7fffffffu,
+                       log_size, tw, ctx().gen_pow2);
+    TSTWO_LAUNCH_CHECK();
+    if (itw) return tstwo_m31_batch_inverse(tw, itw, n);   // backend/cpu/circle.ts:223-239
+    return TSTWO_OK;
+}
+
+int tstwo_poly_extend(const u32 *src, u32 log_src, u32 *dst, u32 log_dst) {
+    TSTWO_REQUIRE_READY();
+    if (log_dst < log_src) return set_error(TSTWO_ERR_LOG_SIZE, "log size too small");
+    size_t ns = (size_t)1 << log_src, nd = (size_t)1 << log_dst;
+    hipLaunchKernelGGL(k_extend, dim3(capped_blocks(nd, 256)), dim3(256), 0, ctx().stream, src, ns, dst, nd);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+// fri.hip — FriOps (fold_line, fold_circle_into_line, decompose) and PolyOps.eval_at_point.
+//
+// A FRI fold is one inverse-CFFT layer followed by f0 + alpha*f1: the per-output
+// twiddle domain.at(bitrev(2i)).x^-1 (resp. .y^-1) that the reference recomputes per element with a
+// scalar multiplication and a Fermat inverse (fri.ts:138-141,180-183) is a slice of the inverse
+// twiddle tree.  One lane per output row on SoA QM31 (4 coalesced 8-byte loads, 4 coalesced stores).
+// Algorithmic bytes per output row: fold_line 48 (32 in + 16 out), fold_circle_into_line 64
+// (32 src + 16 dst in + 16 dst out).
+#include "common.h"
+#include "host_field.h"
+
+using namespace tstwo;
+
+namespace {
+
+__device__ __forceinline__ qm31 load_pair_fold(const CSoa4 &in, size_t i, u32 t, qm31 *f0_out) {
+    // (f0, f1) = ibutterfly(in[2i], in[2i+1], t) per coordinate (fft.ts:25-30)
+    uint2 a = *reinterpret_cast<const uint2 *>(in.p[0] + 2 * i);
+    uint2 b = *reinterpret_cast<const uint2 *>(in.p[1] + 2 * i);
+    uint2 c = *reinterpret_cast<const uint2 *>(in.p[2] + 2 * i);
+    uint2 d = *reinterpret_cast<const uint2 *>(in.p[3] + 2 * i);
+    *f0_out = {m31_add(a.x, a.y), m31_add(b.x, b.y), m31_add(c.x, c.y), m31_add(d.x, d.y)};
+    qm31 diff = {m31_sub(a.x, a.y), m31_sub(b.x, b.y), m31_sub(c.x, c.y), m31_sub(d.x, d.y)};
+    return qm31_mul_m31(diff, t);
+}
+
+// fri.ts:120-152.  inv_x[i] = domain.at(bitrev(2i)).x^-1.
+__global__ void __launch_bounds__(256) k_fold_line(CSoa4 in, Soa4 out, size_t n_out, const u32 *__restrict__ inv_x, qm31 alpha) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        qm31 f0;
+        qm31 f1 = load_pair_fold(in, i, inv_x[i], &f0);
+        qm31 r = qm31_add(f0, qm31_mul(alpha, f1));
+        out.p[0][i] = r.a; out.p[1][i] = r.b; out.p[2][i] = r.c; out.p[3][i] = r.d;
+    }
+}
+
+// fri.ts:162-192.  Twiddle = circle-layer inverse twiddle: either explicit inv_y[i], or derived from the
+// layer-1 slice of the inverse tree: +-seg1[(i>>1)^1], negative iff (i ^ (i>>1)) & 1.
+template <bool FROM_TREE>
+__global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t n_out, const u32 *__restrict__ twp,
+                                                    qm31 alpha, qm31 alpha_sq) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
+        u32 t;
+        if (FROM_TREE) {
+            t = twp[(i >> 1) ^ 1];
+            if ((i ^ (i >> 1)) & 1) t = m31_neg(t);
+        } else {
+            t = twp[i];
+        }
+        qm31 f0;
+        qm31 f1 = load_pair_fold(src, i, t, &f0);
+        qm31 fp = qm31_add(qm31_mul(alpha, f1), f0);
+        qm31 cur = {dst.p[0][i], dst.p[1][i], dst.p[2][i], dst.p[3][i]};
+        qm31 r = qm31_add(qm31_mul(cur, alpha_sq), fp);
+        dst.p[0][i] = r.a; dst.p[1][i] = r.b; dst.p[2][i] = r.c; dst.p[3][i] = r.d;
+    }
+}
+
+// backend/cpu/fri.ts:97-123: sums of the two halves of each coordinate column (exact in u64).
+__global__ void __launch_bounds__(256) k_half_sums(CSoa4 in, size_t n, unsigned long long *sums /* [4][2] */) {
+    __shared__ unsigned long long sh[256 / 64];
+    const u32 coord = blockIdx.y, halfsel = blockIdx.z;
+    const size_t half = n / 2;
+    const u32 *p = in.p[coord] + (halfsel ? half : 0);
+    const size_t cnt = halfsel ? n - half : half;
+    unsigned long long acc = 0;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) acc += p[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = sh[0] + sh[1] + sh[2] + sh[3];
+        atomicAdd(&sums[coord * 2 + halfsel], tot);
+    }
+}
+// backend/cpu/fri.ts:133-164: g = f - lambda on the first half, f + lambda on the second (n == 1: f - lambda)
+__global__ void __launch_bounds__(256) k_decompose_apply(CSoa4 in, Soa4 out, size_t n, qm31 lambda) {
+    const u32 coord = blockIdx.y;
+    const u32 lam = coord == 0 ? lambda.a : coord == 1 ? lambda.b : coord == 2 ? lambda.c : lambda.d;
+    const size_t half = n / 2;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        u32 v = in.p[coord][i];
+        out.p[coord][i] = (i < half || n == 1) ? m31_sub(v, lam) : m31_add(v, lam);
+    }
+}
+
+// ---------------------------------------------------------------- eval_at_point
+// fold (poly/utils.ts:36-59) bottom-up: every lane folds 2^S consecutive inputs with the S innermost
+// remaining factors; factors are ordered innermost-first: [y, x, pi(x), pi^2(x), ...] (circle.ts:61-66).
+struct FoldFactors { qm31 f[5]; };
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_fold_chunk(const u32 *__restrict__ coeffs, const qm31 *__restrict__ partial_in,
+                                                   qm31 *__restrict__ partial_out, size_t n_out, int S, FoldFactors ff) {
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    qm31 v[32];
+    const int cnt = 1 << S;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (j < cnt) {
+            if (FIRST) v[j] = qm31_from_m31(coeffs[(o << S) + j]);
+            else v[j] = partial_in[(o << S) + j];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        if (s < S) {
+#pragma unroll
+            for (int j = 0; j < (16 >> s); j++)
+                if (j < (cnt >> (s + 1))) v[j] = qm31_add(v[2 * j], qm31_mul(v[2 * j + 1], ff.f[s]));
+        }
+    }
+    partial_out[o] = v[0];
+}
+
+unsigned capped_blocks(size_t work_items, unsigned threads) {
+    unsigned blocks = ceil_div(work_items, threads);
+    unsigned cap = (unsigned)ctx().n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    return blocks ? blocks : 1;
+}
+qm31 to_q(const u32 a[4]) { return {a[0], a[1], a[2], a[3]}; }
+qm31 to_q(host::Q a) { return {a.v[0], a.v[1], a.v[2], a.v[3]}; }
+host::Q to_hq(const u32 a[4]) { host::Q q; for (int i = 0; i < 4; i++) q.v[i] = a[i]; return q; }
+
+}  // namespace
+
+extern "C" {
+
+int tstwo_fri_fold_line_tw(const u32 *const in[4], u32 log_n, const u32 *inv_x, const u32 alpha[4], u32 *const out[4]) {
+    TSTWO_REQUIRE_READY();
+    if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
+    if (log_n > 31) return set_error(TSTWO_ERR_BAD_ARG, "fold_line: log size out of range");
+    size_t n_out = (size_t)1 << (log_n - 1);
+    CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, to_q(alpha));
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_fri_fold_line(const u32 *const in[4], u32 log_n, const u32 *itw, u32 tw_log, const u32 alpha[4], u32 *const out[4]) {
+    if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
+    if (tw_log > 31 || log_n > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    // level of the tree whose coset has log size log_n: 2^(log_n-1) entries starting 2^log_n before the end
+    const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << log_n);
+    return tstwo_fri_fold_line_tw(in, log_n, seg, alpha, out);
+}
+
+static int fold_circle_common(bool from_tree, u32 *const dst[4], size_t dst_len, const u32 *const src[4], u32 log_n,
+                              const u32 *twp, const u32 alpha[4]) {
+    TSTWO_REQUIRE_READY();
+    if (log_n == 0 || log_n > 31 || (((size_t)1 << log_n) >> 1) != dst_len)
+        return set_error(TSTWO_ERR_LEN_MISMATCH, "fold_circle_into_line: Length mismatch between src and dst after considering fold step.");
+    host::Q a = to_hq(alpha);
+    host::Q a2 = host::qmul(a, a);
+    Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
+    CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
+    unsigned blocks = capped_blocks(dst_len, 256);
+    if (from_tree)
+        hipLaunchKernelGGL(k_fold_circle<true>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2));
+    else
+        hipLaunchKernelGGL(k_fold_circle<false>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2));
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_fri_fold_circle_into_line_tw(u32 *const dst[4], size_t dst_len, const u32 *const src[4], u32 log_n,
+                                       const u32 *inv_y, const u32 alpha[4]) {
+    return fold_circle_common(false, dst, dst_len, src, log_n, inv_y, alpha);
+}
+
+int tstwo_fri_fold_circle_into_line(u32 *const dst[4], size_t dst_len, const u32 *const src[4], u32 log_n,
+                                    const u32 *itw, u32 tw_log, const u32 alpha[4]) {
+    if (log_n == 0 || log_n > 31 || (((size_t)1 << log_n) >> 1) != dst_len)
+        return set_error(TSTWO_ERR_LEN_MISMATCH, "fold_circle_into_line: Length mismatch between src and dst after considering fold step.");
+    if (log_n < 3) return set_error(TSTWO_ERR_BAD_ARG, "fold_circle_into_line: log_n < 3 needs explicit twiddles (tstwo_fri_fold_circle_into_line_tw)");
+    if (tw_log > 31 || log_n - 1 > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (log_n - 1));   // layer-1 slice, 2^(log_n-2) entries
+    return fold_circle_common(true, dst, dst_len, src, log_n, seg1, alpha);
+}
+
+int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32 lambda[4]) {
+    TSTWO_REQUIRE_READY();
+    if (n == 0) return set_error(TSTWO_ERR_BAD_ARG, "decompose: empty evaluation");
+    Context &c = ctx();
+    int rc = ensure_scratch(64);
+    if (rc) return rc;
+    unsigned long long *sums = (unsigned long long *)c.scratch;
+    TSTWO_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(unsigned long long), c.stream));
+    CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    unsigned blocks = ceil_div(n, 256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_half_sums, dim3(blocks, 4, 2), dim3(256), 0, c.stream, i4, n, sums);
+    TSTWO_LAUNCH_CHECK();
+    unsigned long long h[8];
+    TSTWO_HIP(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    // lambda = (a_sum - b_sum) / n  (n == 1: first half empty -> lambda = -f[0])
+    u32 n_inv = host::inv((u32)(n % host::P));
+    qm31 lam;
+    u32 l[4];
+    for (int k = 0; k < 4; k++) {
+        u32 a = (u32)(h[2 * k] % host::P), b = (u32)(h[2 * k + 1] % host::P);
+        l[k] = host::mul(host::sub(a, b), n_inv);
+    }
+    lam = {l[0], l[1], l[2], l[3]};
+    hipLaunchKernelGGL(k_decompose_apply, dim3(capped_blocks(n, 256), 4), dim3(256), 0, c.stream, i4, o4, n, lam);
+    TSTWO_LAUNCH_CHECK();
+    for (int k = 0; k < 4; k++) lambda[k] = l[k];
+    return TSTWO_OK;
+}
+
+int tstwo_eval_at_point(const u32 *coeffs, u32 log_size, const u32 px[4], const u32 py[4], u32 out[4]) {
+    TSTWO_REQUIRE_READY();
+    if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: log size out of range");
+    Context &c = ctx();
+    if (log_size == 0) {   // circle.ts:53-59
+        u32 v;
+        TSTWO_HIP(hipMemcpyAsync(&v, coeffs, 4, hipMemcpyDeviceToHost, c.stream));
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        out[0] = v; out[1] = out[2] = out[3] = 0;
+        return TSTWO_OK;
+    }
+    // innermost-first factors: y, x, pi(x), ... (circle.ts:61-67 before the reverse)
+    host::Q fac[32];
+    fac[0] = to_hq(py);
+    host::Q x = to_hq(px), one;
+    one.v[0] = 1; one.v[1] = one.v[2] = one.v[3] = 0;
+    for (u32 i = 1; i < log_size; i++) {
+        fac[i] = x;
+        host::Q sx = host::qmul(x, x);
+        x = host::qsub(host::qadd(sx, sx), one);   // circle.ts:37-40
+    }
+    size_t n1 = (size_t)1 << (log_size > 5 ? log_size - 5 : 0);
+    int rc = ensure_scratch(2 * (n1 + 64) * sizeof(qm31));
+    if (rc) return rc;
+    qm31 *bufA = (qm31 *)c.scratch, *bufB = bufA + n1 + 32;
+    u32 done = 0;
+    size_t cur = (size_t)1 << log_size;
+    bool first = true;
+    qm31 *src = nullptr, *dst = bufA;
+    while (done < log_size) {
+        int S = (int)(log_size - done < 5 ? log_size - done : 5);
+        size_t n_out = cur >> S;
+        FoldFactors ff;
+        for (int s = 0; s < 5; s++) ff.f[s] = s < S ? to_q(fac[done + s]) : qm31{0, 0, 0, 0};
+        if (first)
+            hipLaunchKernelGGL(k_fold_chunk<true>, dim3(ceil_div(n_out, 256)), dim3(256), 0, c.stream, coeffs, (const qm31 *)nullptr, dst, n_out, S, ff);
+        else
+            hipLaunchKernelGGL(k_fold_chunk<false>, dim3(ceil_div(n_out, 256)), dim3(256), 0, c.stream, (const u32 *)nullptr, (const qm31 *)src, dst, n_out, S, ff);
+        first = false;
+        done += (u32)S;
+        cur = n_out;
+        src = dst;
+        dst = (dst == bufA) ? bufB : bufA;
+    }
+    TSTWO_LAUNCH_CHECK();
+    qm31 r;
+    TSTWO_HIP(hipMemcpyAsync(&r, src, sizeof(r), hipMemcpyDeviceToHost, c.stream));
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    out[0] = r.a; out[1] = r.b; out[2] = r.c; out[3] = r.d;
+    return TSTWO_OK;
+}
+
+}  // extern "C"
