@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 5, column-sharded; weak scaling): every rank owns 32 trace columns
+of 2^22 M31 words (256 columns at 8 GPUs).  One step = PolyOps.evaluate (Circle FFT) of the rank's
+32 columns on CanonicCoset(22).circleDomain(), then MerkleProver.commit (Blake2s) over them, then
+an all-gather of the ranks' 32-byte Merkle roots (RCCL; N > 1 only).  Inputs are synthetic
+(SplitMix64 seeds 100+c) and resident in HBM before the timed region; twiddles are prebuilt.
+The transform is data-oblivious, so each step re-evaluates the previous step's output in place
+(uniform canonical M31 columns again) — no work is skipped or cached.
+
+Rank 0 prints ONE JSON line:  value = (all ranks' columns * 2^22 elements * K) / max-over-ranks time.
+`roofline` prices the dominant kernel (the CFFT pass kernel) against the 8 TB/s HBM roofline with the
+algorithmic bytes of SURVEY.md §8(d); `cpu_baseline` times the CPU oracle on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_SIZE = 22
+COLS_PER_GPU = 32
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def splitmix_column(seed: int, n: int) -> np.ndarray:
+    """Uniform M31 column from SplitMix64(seed) with rejection of values >= P (vectorised)."""
+    P = 2147483647
+    out = np.empty(n, dtype=np.uint32)
+    filled = 0
+    state = np.uint64(seed)
+    gamma = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        while filled < n:
+            m = n - filled + 64
+            s = state + gamma * np.arange(1, m + 1, dtype=np.uint64)
+            state = s[-1]
+            z = s
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            v = (z >> np.uint64(33)).astype(np.uint32)
+            v = v[v < P][: n - filled]
+            out[filled:filled + v.size] = v
+            filled += v.size
+    return out
+
+
+def cpu_baseline(sample_cols: int):
+    """CPU oracle (oracle/, 'port') on a bounded sample: `sample_cols` of the 32 columns, same log size:
+    CFFT evaluate + Merkle commit over those columns, one thread."""
+    from oracle import oracle as orc
+    n = LOG_SIZE
+    half = orc.lib().orc_half_odds_initial(n - 1)
+    tw, _ = orc.precompute_twiddles(half, n - 1, inverse=False)       # untimed, like the GPU side
+    cols = [splitmix_column(100 + c, 1 << n) for c in range(sample_cols)]
+    t0 = time.perf_counter()
+    evs = [orc.cfft_evaluate(c, n, half, tw, n - 1) for c in cols]
+    t1 = time.perf_counter()
+    orc.merkle_commit(evs, [n] * sample_cols)
+    t2 = time.perf_counter()
+    return {
+        "value": sample_cols * (1 << n) / (t2 - t0),
+        "unit": "elems/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sample_cols} of {COLS_PER_GPU} columns x 2^{n}: oracle CFFT evaluate ({t1 - t0:.2f} s) + "
+                  f"Blake2s Merkle commit over them ({t2 - t1:.2f} s), 1 thread; host has {os.cpu_count()} cores",
+        "cfft_butterflies_per_s": sample_cols * n * (1 << (n - 1)) / (t1 - t0),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cols", type=int, default=COLS_PER_GPU, help="columns per GPU")
+    ap.add_argument("--log-size", type=int, default=LOG_SIZE)
+    ap.add_argument("--cpu-cols", type=int, default=4, help="columns in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n, n_cols = args.log_size, args.cols
+    N = 1 << n
+
+    # torch is plumbing only (RCCL all-gather of roots, barrier).  It must be imported BEFORE the HIP library is
+    # dlopen'ed so that both bind the same HIP runtime (same soname) in this process.
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from tstwo_amd import _lib as L
+    from tstwo_amd.backend import HipBackend, shard_columns
+
+    L.init(local_rank)
+    backend = HipBackend()
+
+    # ---- the rank's shard of the (world * n_cols) trace columns, resident in HBM
+    my_cols = shard_columns(world * n_cols, world, rank)
+    dev_cols = []
+    for c in my_cols:
+        b = L.DeviceBuffer(4 * N)
+        b.upload(splitmix_column(100 + c, N))
+        dev_cols.append(b)
+    col_ptrs = L.ptr_array([b.ptr for b in dev_cols])
+    half_initial = backend.canonic_half_coset_initial(n)
+    tw = L.DeviceBuffer(4 * (N // 2))
+    L.call("tstwo_twiddles_build", half_initial, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
+    layers = L.DeviceBuffer(32 * ((2 << n) - 1))
+    log_sizes = L.u32x([n] * n_cols)
+    roots_local = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    roots_all = torch.zeros(32 * world, dtype=torch.uint8, device="cuda")
+    L.sync()
+
+    # HIP events on the library's stream, three per timed step, read after the timed region
+    evs = [[L.Event() for _ in range(3)] for _ in range(args.steps)]
+
+    def step(ev):
+        if ev:
+            ev[0].record()
+        L.call("tstwo_cfft_evaluate", col_ptrs, n_cols, n, half_initial, C.c_void_p(tw.ptr), n - 1)
+        if ev:
+            ev[1].record()
+        L.call("tstwo_merkle_commit", col_ptrs, log_sizes, n_cols, C.c_void_p(layers.ptr), None)
+        if ev:
+            ev[2].record()
+        if world > 1:   # the only exchange on the path: 32-byte roots over RCCL/xGMI
+            L.call("tstwo_copy", C.c_void_p(roots_local.data_ptr()), C.c_void_p(layers.ptr), 32)
+            L.sync()
+            dist.all_gather_into_tensor(roots_all, roots_local)
+
+    def barrier():
+        L.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        L.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(evs[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t_cfft = sum(e[0].elapsed_ms(e[1]) for e in evs)
+    t_merkle = sum(e[1].elapsed_ms(e[2]) for e in evs)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # roots of all ranks must have arrived and rank r's slot must hold rank r's root
+        mine = bytes(roots_all[32 * rank:32 * rank + 32].cpu().numpy().tobytes())
+        assert mine == bytes(layers.download(np.uint8, 32).tobytes())
+
+    if rank == 0:
+        steps = args.steps
+        total_elems = world * n_cols * N * steps
+        cfft_ms = t_cfft / steps
+        merkle_ms = t_merkle / steps
+        # dominant kernel: k_cfft_pass<false>, launched (passes) times per step over all columns.
+        passes = 1 if n <= 13 else 1 + -(-(n - 13) // 9)
+        algo_bytes_transform = 8.0 * N * n_cols                     # 8*N per column transform
+        algo_bytes_launch = algo_bytes_transform / passes
+        launch_ms = cfft_ms / passes
+        achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9
+        merkle_bytes = (4.0 * n_cols + 64.0) * N                    # 4*C*N read + 64*N written
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_cfft_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "M31 CFFT elems/sec at log_size=22 (per step: CFFT evaluate + Blake2s Merkle commit + root all-gather)",
+            "value": total_elems / elapsed,
+            "unit": "elems/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5 shard: {n_cols} columns x 2^{n} per GPU "
+                                   f"({world * n_cols} columns total), CircleDomain of CanonicCoset({n}); "
+                                   "evaluate + per-GPU Merkle tree" + (" + RCCL all-gather of roots" if world > 1 else ""),
+                       "log_size": n, "columns_per_gpu": n_cols, "parallelism": f"column-shard x{world}"},
+            "cfft_ms": cfft_ms,
+            "cfft_butterflies_per_s": n_cols * n * (N // 2) / (cfft_ms * 1e-3),
+            "cfft_elems_per_s": n_cols * N / (cfft_ms * 1e-3),
+            "merkle_ms": merkle_ms,
+            "merkle_GBps": merkle_bytes / (merkle_ms * 1e-3) / 1e9,
+            "merkle_frac_of_hbm_peak": merkle_bytes / (merkle_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_cfft_pass<false>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "launches_per_step": passes, "avg_launch_ms": launch_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch},
+            "device": L.device_name(),
+        }
+        if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_cols)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

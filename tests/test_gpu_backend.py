@@ -1,0 +1,301 @@
+"""-m gpu tests of the host-side mirror (HipBackend & friends), written to read like the reference's own tests:
+packages/core/test/backend/backend.test.ts, test/backend/cpu/circle.test.ts, test/poly/circleEvaluation.test.ts,
+test/fri.test.ts, test/backend/cpu/fri.test.ts, test/vcs/prover.test.ts, test/backend/cpu/quotients.test.ts."""
+import numpy as np
+import pytest
+
+from conftest import P, column, rand_column
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import tstwo_amd as T  # noqa: E402
+from tstwo_amd import _lib as L  # noqa: E402
+
+OL = orc.lib()
+
+
+@pytest.fixture(scope="module")
+def backend():
+    L.init(0)
+    return T.HipBackend()
+
+
+# ---------------------------------------------------------------- backend.test.ts
+def test_backend_name_and_columns(backend):
+    assert backend.name == "HipBackend"
+    col = backend.createBaseFieldColumn([T.M31(1), T.M31(2), T.M31(3), T.M31(4)])
+    assert col.len() == 4 and not col.isEmpty()
+    assert col.at(2) == T.M31(3)
+    col.set(1, T.M31(42))
+    assert [m.value for m in col.toCpu()] == [1, 42, 3, 4]
+    with pytest.raises(IndexError, match="out of bounds"):
+        col.at(4)
+    with pytest.raises(IndexError, match="out of bounds"):
+        col.set(-1, T.M31(0))
+    z = T.HipColumn.zeros(5)
+    assert [m.value for m in z.toCpu()] == [0] * 5
+    assert T.HipColumn.uninitialized(7).len() == 7
+    assert T.HipColumn([]).isEmpty()
+    s = backend.createSecureFieldColumn([T.QM31.from_u32_unchecked(1, 2, 3, 4), T.QM31.from_u32_unchecked(5, 6, 7, 8)])
+    assert s.at(1) == T.QM31.from_u32_unchecked(5, 6, 7, 8)
+    s.set(0, T.QM31.from_u32_unchecked(9, 9, 9, 9))
+    assert [q.tup() for q in s.to_vec()] == [(9, 9, 9, 9), (5, 6, 7, 8)]
+    # value semantics: constructing from an array copies it (cpu/index.ts:89)
+    a = np.array([1, 2, 3, 4], dtype=np.uint32)
+    c = T.HipColumn(a)
+    a[0] = 99
+    assert c.at(0) == T.M31(1)
+
+
+def test_bit_reverse_column(backend):
+    col = backend.createBaseFieldColumn(list(range(8)))
+    backend.bitReverseColumn(col)
+    assert [m.value for m in col.toCpu()] == [0, 4, 2, 6, 1, 5, 3, 7]
+    for bad in (3, 6):
+        with pytest.raises(L.TstwoError, match="length is not power of two"):
+            backend.bitReverseColumn(backend.createBaseFieldColumn(list(range(bad))))
+    with pytest.raises(L.TstwoError, match="length is not power of two"):
+        backend.bitReverseColumn(T.HipColumn([]))
+    sec = T.SecureColumnByCoords.from_numpy([np.arange(4, dtype=np.uint32) + 10 * k for k in range(4)])
+    backend.bitReverseColumn(sec)
+    assert sec.to_numpy()[1].tolist() == [10, 12, 11, 13]
+
+
+def test_field_column_ops_and_batch_inverse(backend):
+    n = 1 << 20                                             # BASELINE config 1 size
+    a, b = rand_column(1, n), rand_column(2, n, nonzero=True)
+    da, db = T.HipColumn(a), T.HipColumn(b)
+    assert (backend.add(da, db).to_numpy() == orc.col_op("add", a, b)).all()
+    assert (backend.mul(da, db).to_numpy() == orc.col_op("mul", a, b)).all()
+    assert (backend.sub(da, db).to_numpy() == orc.col_op("sub", a, b)).all()
+    assert (backend.neg(da).to_numpy() == orc.col_op("neg", a)).all()
+    inv = backend.batchInverse(db)
+    assert (inv.to_numpy() == orc.m31_batch_inverse(b)).all()
+    assert (backend.mul(inv, db).to_numpy() == 1).all()
+    with pytest.raises(L.TstwoError, match="0 has no inverse"):
+        backend.batchInverse(T.HipColumn([1, 2, 0, 4]))
+
+
+# ---------------------------------------------------------------- circle.test.ts / circleEvaluation.test.ts
+@pytest.mark.parametrize("log_size", [1, 2, 3])
+def test_evaluate_matches_eval_at_point(log_size):
+    """circle.test.ts:52-97 (sizes 2/4/8) — with the TRUE ordering (no log-3 swap): domain.at(i) <-> bitrev index."""
+    coeffs = [T.M31(i + 1) for i in range(1 << log_size)]
+    poly = T.HipCirclePoly(coeffs)
+    domain = T.CanonicCoset(log_size).circleDomain()
+    ev = poly.evaluate(domain).bitReverse().toCpu()
+    for i in range(domain.size()):
+        p = domain.at(i)
+        pt = T.CirclePoint(T.QM31.from_(p.x), T.QM31.from_(p.y))
+        assert poly.evalAtPoint(pt) == T.QM31.from_(ev[i]), (log_size, i)
+
+
+def test_log3_compat_swap():
+    coeffs = rand_column(3, 8)
+    domain = T.CanonicCoset(3).circleDomain()
+    true = T.HipCirclePoly(coeffs).evaluate(domain).values.to_numpy()
+    T.HipCirclePoly.compatLog3Swap = True
+    try:
+        compat = T.HipCirclePoly(coeffs).evaluate(domain)
+        v = compat.values.to_numpy()
+        assert v[5] == true[7] and v[7] == true[5] and (np.delete(v, [5, 7]) == np.delete(true, [5, 7])).all()
+        assert (compat.interpolate().coeffs.to_numpy() == coeffs).all()
+    finally:
+        T.HipCirclePoly.compatLog3Swap = False
+
+
+@pytest.mark.parametrize("log_size", [1, 2, 3, 4, 5, 6, 10, 14])
+def test_interpolate_evaluate_roundtrip(log_size):
+    """circle.test.ts:236-256."""
+    coeffs = rand_column(log_size, 1 << log_size)
+    domain = T.CanonicCoset(log_size).circleDomain()
+    ev = T.HipCirclePoly(coeffs).evaluate(domain)
+    assert (ev.interpolate().coeffs.to_numpy() == coeffs).all()
+    tw = T.precompute_twiddles(T.Coset.half_odds(log_size + 2))          # a bigger tree serves the domain
+    ev2 = T.HipCirclePoly(coeffs).evaluateWithTwiddles(domain, tw)
+    assert (ev2.values.to_numpy() == ev.values.to_numpy()).all()
+    assert (ev2.interpolateWithTwiddles(tw).coeffs.to_numpy() == coeffs).all()
+
+
+def test_evaluate_on_extended_domain_and_errors():
+    coeffs = rand_column(9, 1 << 5)
+    poly = T.HipCirclePoly(coeffs)
+    big = T.CanonicCoset(8).circleDomain()
+    ev = poly.evaluate(big)                                            # blowup 3: zero-extension fused by the wrapper
+    ext = np.concatenate([coeffs, np.zeros((1 << 8) - 32, dtype=np.uint32)])
+    otw, _ = orc.precompute_twiddles(big.halfCoset.initial_index.value, 7, inverse=False)
+    assert (ev.values.to_numpy() == orc.cfft_evaluate(ext, 8, big.halfCoset.initial_index.value, otw, 7)).all()
+    assert (poly.extend(7).coeffs.to_numpy()[:32] == coeffs).all() and poly.extend(7).logSize() == 7
+    with pytest.raises(ValueError, match="log size too small"):
+        poly.extend(3)
+    with pytest.raises(ValueError, match="log size too small"):
+        poly.evaluate(T.CanonicCoset(3).circleDomain())
+    with pytest.raises(ValueError, match="twiddle tree mismatch"):
+        poly.evaluateWithTwiddles(big, T.precompute_twiddles(T.Coset.half_odds(4)))
+    with pytest.raises(ValueError, match="twiddle tree mismatch"):
+        poly.evaluateWithTwiddles(big, T.precompute_twiddles(T.Coset.half_odds(9).shift(T.CirclePointIndex(12345))))
+    with pytest.raises(L.TstwoError, match="0 has no inverse"):     # a subgroup coset contains x = 0 (reference throws too)
+        T.precompute_twiddles(T.Coset.subgroup(9))
+
+
+def test_batched_poly_ops_and_secure_evaluation():
+    n = 9
+    domain = T.CanonicCoset(n).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    cols = [rand_column(20 + c, 1 << n) for c in range(5)]
+    evs = T.evaluate_polynomials([T.HipCirclePoly(c) for c in cols], domain, tw)
+    otw, _ = orc.precompute_twiddles(domain.halfCoset.initial_index.value, n - 1, inverse=False)
+    for c, e in zip(cols, evs):
+        assert (e.values.to_numpy() == orc.cfft_evaluate(c, n, domain.halfCoset.initial_index.value, otw, n - 1)).all()
+    back = T.interpolate_columns(evs, tw)
+    for c, p in zip(cols, back):
+        assert (p.coeffs.to_numpy() == c).all()
+    sec = T.SecureEvaluation(domain, T.SecureColumnByCoords([e.values for e in evs[:4]]))
+    for c, p in zip(cols[:4], sec.interpolateWithTwiddles(tw)):
+        assert (p.coeffs.to_numpy() == c).all()
+
+
+# ---------------------------------------------------------------- fri.test.ts / backend/cpu/fri.test.ts
+def test_fold_line_is_2_fe_plus_alpha_fo():
+    """fri.test.ts:206-254: folding the evaluations of f on D equals 2*(f_e + alpha*f_o) on D.double()."""
+    log = 7
+    alpha = T.QM31.from_u32_unchecked(2, 1, 0, 0)   # BaseField-like alpha keeps the check in M31 x QM31
+    alpha = T.QM31.from_u32_unchecked(19283, 1, 2, 3)
+    domain = T.LineDomain(T.Coset.half_odds(log))
+    # f(x) = sum c_k x^k evaluated with python ints; even/odd parts in pi(x) = 2x^2 - 1
+    rng = np.random.default_rng(5)
+    even = [int(v) for v in rng.integers(0, P, size=4)]
+    odd = [int(v) for v in rng.integers(0, P, size=4)]
+
+    def poly(cs, x):
+        acc = 0
+        for c in reversed(cs):
+            acc = (acc * x + c) % P
+        return acc
+
+    def f(x):
+        px = (2 * x * x - 1) % P
+        return (poly(even, px) + x * poly(odd, px)) % P
+
+    vals_nat = [f(domain.at(i).value) for i in range(domain.size())]
+    vals = [vals_nat[T.bit_reverse_index(i, log)] for i in range(domain.size())]
+    ev = T.LineEvaluation(domain, T.SecureColumnByCoords.from_([(v, 0, 0, 0) for v in vals]))
+    tw = T.precompute_twiddles(T.Coset.half_odds(log))
+    folded = T.fold_line(ev, alpha, tw)
+    assert folded.domain() == domain.double() and folded.len() == domain.size() // 2
+    got = folded.values.to_vec()
+    d2 = domain.double()
+    for i in range(d2.size()):
+        x = d2.at(T.bit_reverse_index(i, log - 1)).value
+        exp = T.QM31.from_(T.M31(poly(even, x))).add(alpha.mulM31(T.M31(poly(odd, x)))).double()
+        assert got[i] == exp
+    # without a tree (or with a non-matching one) the per-element path gives the same values
+    assert T.fold_line(ev, alpha).values.to_numpy()[0].tolist() == folded.values.to_numpy()[0].tolist()
+    with pytest.raises(ValueError, match="fold_line: Evaluation too small"):
+        T.fold_line(T.LineEvaluation(T.LineDomain(T.Coset.half_odds(0)), T.SecureColumnByCoords.zeros(1)), alpha)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_fold_circle_into_line_vs_oracle(n):
+    alpha = T.QM31.from_u32_unchecked(19283, 1, 2, 3)
+    domain = T.CanonicCoset(n).circleDomain()
+    src_np = [rand_column(30 + k, 1 << n) for k in range(4)]
+    dst_np = [rand_column(40 + k, 1 << (n - 1)) for k in range(4)]
+    src = T.SecureEvaluation(domain, T.SecureColumnByCoords.from_numpy(src_np))
+    dst = T.LineEvaluation(T.LineDomain(domain.halfCoset), T.SecureColumnByCoords.from_numpy(dst_np))
+    tw = T.precompute_twiddles(T.Coset.half_odds(max(n - 1, 1) + 1))
+    T.fold_circle_into_line(dst, src, alpha, tw)
+    exp = orc.fold_circle_into_line(dst_np, src_np, n, domain.halfCoset.initial_index.value, alpha.tup())
+    for g, e in zip(dst.values.to_numpy(), exp):
+        assert (g == e).all()
+    with pytest.raises(ValueError, match="fold_circle_into_line: Length mismatch"):
+        T.fold_circle_into_line(T.LineEvaluation.new_zero(T.LineDomain(T.Coset.half_odds(n + 1))), src, alpha)
+
+
+def test_decompose_reconstruction():
+    """backend/cpu/fri.test.ts:44-72,124-184."""
+    n = 6
+    domain = T.CanonicCoset(n).circleDomain()
+    cols = [rand_column(50 + k, 1 << n) for k in range(4)]
+    g, lam = T.decompose(T.SecureEvaluation(domain, T.SecureColumnByCoords.from_numpy(cols)))
+    exp, elam = orc.decompose(cols)
+    assert lam.tup() == elam
+    for a, b in zip(g.values.to_numpy(), exp):
+        assert (a == b).all()
+
+
+# ---------------------------------------------------------------- vcs/prover.test.ts, backend/cpu/blake2.test.ts
+def test_merkle_prover_commit_and_layers(golden):
+    e = golden["merkle_lcg"]                      # prepareMerkle data (vcs/test_utils.ts:47-144)
+    cols = [T.HipColumn(np.array(c, dtype=np.uint32)) for c in e["cols"]]
+    tree = T.MerkleProver.commit(cols)
+    assert tree.root().hex() == e["root"]
+    assert [[h.hex() for h in layer.toCpu()] for layer in tree.layers] == e["layers"]
+    assert len(tree.layers[0]) == 1 and tree.layers[0].at(0) == tree.root()
+    empty = T.MerkleProver.commit([])
+    assert empty.root().hex() == golden["blake2s_kat"][""]
+    # commitOnLayer == hashNode per node (backend/cpu/blake2.test.ts:55-176)
+    vals = [rand_column(60 + c, 8) for c in range(3)]
+    layer = T.HipMerkleOps.commitOnLayer(3, None, [T.HipColumn(v) for v in vals])
+    for i, h in enumerate(layer.toCpu()):
+        assert h == orc.hash_node(None, [v[i] for v in vals])
+    up = T.HipMerkleOps.commitOnLayer(2, layer, [T.HipColumn(v[:4]) for v in vals[:1]])
+    hs = layer.toCpu()
+    for i, h in enumerate(up.toCpu()):
+        assert h == orc.hash_node((hs[2 * i], hs[2 * i + 1]), [vals[0][i]])
+
+
+# ---------------------------------------------------------------- quotients
+def test_quotients_are_low_degree():
+    """pcs/quotients.ts:179-201 (Rust test_quotients_are_low_degree): log 7 poly, blowup 1, coeff qm31(1,2,3,4)."""
+    LOG_SIZE, LOG_BLOWUP = 7, 1
+    coeffs = rand_column(70, 1 << LOG_SIZE)
+    poly = T.HipCirclePoly(coeffs)
+    eval_domain = T.CanonicCoset(LOG_SIZE + 1).circleDomain()
+    ev = poly.evaluate(eval_domain)
+    point = T.SECURE_FIELD_CIRCLE_GEN
+    value = poly.evalAtPoint(point)
+    coeff = T.QM31.from_u32_unchecked(1, 2, 3, 4)
+    quot_domain = T.CanonicCoset(LOG_SIZE + LOG_BLOWUP).circleDomain()
+    q = T.accumulateQuotients(quot_domain, [ev], coeff, [T.ColumnSampleBatch(point, [(0, value)])], LOG_BLOWUP)
+    tw = T.precompute_twiddles(quot_domain.halfCoset)
+    for p in q.interpolateWithTwiddles(tw):
+        c = p.coeffs.to_numpy()
+        assert not c[1 << LOG_SIZE:].any() and c[: 1 << LOG_SIZE].any()
+    exp = orc.accumulate_quotients(quot_domain.halfCoset.initial_index.value, LOG_SIZE + 1, [ev.values.to_numpy()], coeff.tup(),
+                                   [(point.x.tup(), point.y.tup(), [(0, value.tup())])])
+    for a, b in zip(q.values.to_numpy(), exp):
+        assert (a == b).all()
+
+
+def test_quotients_ts_compat_variant():
+    """The TS port's deviations (per-CM31 conjugation; Pr/Pi from c0.real/c0.imag) as an opt-in: checked against the
+    oracle's generic row loop fed with the same host constants."""
+    from tstwo_amd.quotients import quotientConstants
+    n = 6
+    domain = T.CanonicCoset(n).circleDomain()
+    cols = [rand_column(80 + c, 1 << n) for c in range(2)]
+    point = T.SECURE_FIELD_CIRCLE_GEN
+    vals = [T.QM31.from_u32_unchecked(7, 8, 9, 10), T.QM31.from_u32_unchecked(11, 12, 13, 14)]
+    coeff = T.QM31.from_u32_unchecked(1, 2, 3, 4)
+    batches = [T.ColumnSampleBatch(point, [(0, vals[0]), (1, vals[1])])]
+    got = T.accumulateQuotients(domain, [T.HipColumn(c) for c in cols], coeff, batches, 1, ts_compat=True)
+    lc, bc = quotientConstants(batches, coeff, ts_compat=True)
+    abc = [t.tup() for trip in lc[0] for t in trip]
+    x, y = point.x, point.y
+    exp = orc.accumulate_quotients_consts(domain.halfCoset.initial_index.value, n, cols, [0, 2], [0, 1], abc, [bc[0].tup()],
+                                          [(x.c0.real.value, 0)], [(y.c0.real.value, 0)], [(x.c0.imag.value, 0)], [(y.c0.imag.value, 0)])
+    for a, b in zip(got.values.to_numpy(), exp):
+        assert (a == b).all()
+
+
+def test_accumulate(backend):
+    a = T.SecureColumnByCoords.from_numpy([rand_column(90 + k, 100) for k in range(4)])
+    b = T.SecureColumnByCoords.from_numpy([rand_column(95 + k, 100) for k in range(4)])
+    exp = orc.accumulate(a.to_numpy(), b.to_numpy())
+    T.accumulate(a, b)
+    for x, y in zip(a.to_numpy(), exp):
+        assert (x == y).all()
+    with pytest.raises(ValueError, match="column length mismatch"):
+        T.accumulate(a, T.SecureColumnByCoords.zeros(3))

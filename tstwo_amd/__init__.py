@@ -1,0 +1,19 @@
+"""tstwo_amd — MI355X (gfx950) backend for tstwo's data-parallel Circle-STARK hot path.
+
+Host-side mirror of the reference's Backend / ColumnOps / PolyOps / FriOps / MerkleOps / QuotientOps surface
+over the C ABI of libtstwo_hip.so (include/tstwo_hip.h).  The product path is GPU-only: it fails loudly when
+the HIP library is missing or no GPU is present, and never touches oracle/.
+"""
+from . import _lib  # noqa: F401
+from .backend import HipBackend, HipColumn, SecureColumnByCoords, shard_columns  # noqa: F401
+from .circle import (CanonicCoset, CircleDomain, CirclePoint, CirclePointIndex, Coset, LineDomain,  # noqa: F401
+                     M31_CIRCLE_GEN, SECURE_FIELD_CIRCLE_GEN, bit_reverse_index)
+from .fields import CM31, M31, P, QM31  # noqa: F401
+from .fri import HipFriOps, decompose, fold_circle_into_line, fold_line  # noqa: F401
+from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureEvaluation, TwiddleTree,  # noqa: F401
+                   evaluate_polynomials, interpolate_columns, precompute_twiddles)
+from .quotients import (ColumnSampleBatch, accumulate, accumulateQuotients, generate_secure_powers,  # noqa: F401
+                        quotientConstants)
+from .vcs import DeviceHashLayer, HipMerkleOps, MerkleProver  # noqa: F401
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,197 @@
+"""PolyOps on the GPU: HipCirclePoly / HipCircleEvaluation with the reference's static-method dispatch
+(packages/core/src/backend/cpu/circle.ts:17-208, poly/circle/{poly,evaluation,ops,secure_poly}.ts,
+poly/twiddles.ts, poly/line.ts:241-329)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .backend import HipBackend, HipColumn, SecureColumnByCoords, _vp
+from .circle import CanonicCoset, CircleDomain, CirclePoint, Coset, LineDomain
+from .fields import M31, QM31, as_q4
+
+
+class TwiddleTree:
+    """poly/twiddles.ts:10-29 with device buffers."""
+
+    def __init__(self, root_coset: Coset, twiddles: HipColumn, itwiddles: HipColumn):
+        self.rootCoset = root_coset
+        self.root_coset = root_coset
+        self.twiddles = twiddles
+        self.itwiddles = itwiddles
+
+    @property
+    def log_size(self) -> int:
+        return self.rootCoset.log_size
+
+
+def precompute_twiddles(coset: Coset) -> TwiddleTree:
+    """precomputeTwiddles (backend/cpu/circle.ts:210-239), generated on the device."""
+    n = coset.size()
+    tw, itw = HipColumn.uninitialized(n), HipColumn.uninitialized(n)
+    L.call("tstwo_twiddles_build", coset.initial_index.value, coset.log_size, _vp(tw.ptr), _vp(itw.ptr))
+    return TwiddleTree(coset, tw, itw)
+
+
+def _swap57(col: HipColumn) -> None:
+    """The reference's log_size == 3 output swap (backend/cpu/circle.ts:123-131,145-151), compat only."""
+    v = col.to_numpy()
+    v[5], v[7] = v[7], v[5]
+    col.buf.upload(v)
+
+
+class HipCirclePoly:
+    """CirclePoly<HipBackend> (poly/circle/poly.ts:9-73) + the PolyOps statics of backend/cpu/circle.ts:39-208."""
+
+    compatLog3Swap = False   # True reproduces the reference's TEMPORARY WORKAROUND output order at log 3
+
+    def __init__(self, coeffs):
+        self.coeffs = coeffs if isinstance(coeffs, HipColumn) else HipColumn(coeffs)
+        n = self.coeffs.len()
+        if n == 0 or n & (n - 1):
+            raise ValueError("coeffs length must be a power of two")
+        self._log_size = n.bit_length() - 1
+
+    new = staticmethod(lambda coeffs: HipCirclePoly(coeffs))
+
+    def logSize(self) -> int:
+        return self._log_size
+
+    log_size = logSize
+
+    # ---- instance API (poly.ts:34-59): dispatch through the class statics
+    def evaluate(self, domain: CircleDomain) -> "HipCircleEvaluation":
+        tw = type(self).precomputeTwiddles(domain.halfCoset)
+        return type(self).evaluate_static(self, domain, tw)
+
+    def evaluateWithTwiddles(self, domain, twiddles): return type(self).evaluate_static(self, domain, twiddles)
+    def evalAtPoint(self, point) -> QM31: return type(self).eval_at_point(self, point)
+    def extend(self, log_size): return type(self).extend_static(self, log_size)
+
+    # ---- PolyOps statics
+    @staticmethod
+    def precomputeTwiddles(coset: Coset) -> TwiddleTree:
+        return precompute_twiddles(coset)
+
+    @staticmethod
+    def eval_at_point(poly: "HipCirclePoly", point: CirclePoint) -> QM31:
+        out = (C.c_uint32 * 4)()
+        L.call("tstwo_eval_at_point", _vp(poly.coeffs.ptr), poly.logSize(), L.u32x(as_q4(point.x)), L.u32x(as_q4(point.y)), out)
+        return QM31.from_u32_unchecked(*out)
+
+    @staticmethod
+    def extend_static(poly: "HipCirclePoly", log_size: int) -> "HipCirclePoly":
+        if log_size < poly.logSize():
+            raise ValueError("log size too small")
+        out = HipColumn.uninitialized(1 << log_size)
+        L.call("tstwo_poly_extend", _vp(poly.coeffs.ptr), poly.logSize(), _vp(out.ptr), log_size)
+        return HipCirclePoly(out)
+
+    @staticmethod
+    def evaluate_static(poly: "HipCirclePoly", domain: CircleDomain, twiddles: TwiddleTree) -> "HipCircleEvaluation":
+        return evaluate_polynomials([poly], domain, twiddles)[0]
+
+    @staticmethod
+    def interpolate(eval_: "HipCircleEvaluation", twiddles: TwiddleTree) -> "HipCirclePoly":
+        return interpolate_columns([eval_], twiddles)[0]
+
+
+def _check_tree(domain: CircleDomain, twiddles: TwiddleTree) -> None:
+    if not domain.halfCoset.is_doubling_of(twiddles.rootCoset):
+        raise ValueError("twiddle tree mismatch")                     # backend/cpu/circle.ts:89-91,140-142
+
+
+def evaluate_polynomials(polys, domain: CircleDomain, twiddles: TwiddleTree) -> list:
+    """PolyOps.evaluatePolynomials (poly/circle/ops.ts:89-101), batched: one launch sequence for all columns."""
+    _check_tree(domain, twiddles)
+    n = domain.log_size()
+    outs = []
+    for p in polys:
+        if n < p.logSize():
+            raise ValueError("log size too small")
+        outs.append(HipCirclePoly.extend_static(p, n).coeffs)
+    L.call("tstwo_cfft_evaluate", L.ptr_array([c.ptr for c in outs]), len(outs), n, domain.halfCoset.initial_index.value,
+           _vp(twiddles.twiddles.ptr), twiddles.log_size)
+    if HipCirclePoly.compatLog3Swap and n == 3:
+        for c in outs:
+            _swap57(c)
+    return [HipCircleEvaluation(domain, c) for c in outs]
+
+
+def interpolate_columns(evals, twiddles: TwiddleTree) -> list:
+    """PolyOps.interpolateColumns (poly/circle/ops.ts:73-82), batched over columns of one domain."""
+    if not evals:
+        return []
+    domain = evals[0].domain
+    _check_tree(domain, twiddles)
+    n = domain.log_size()
+    outs = [e.values.clone() for e in evals]
+    if HipCirclePoly.compatLog3Swap and n == 3:
+        for c in outs:
+            _swap57(c)
+    L.call("tstwo_cfft_interpolate", L.ptr_array([c.ptr for c in outs]), len(outs), n, domain.halfCoset.initial_index.value,
+           _vp(twiddles.itwiddles.ptr), twiddles.log_size)
+    return [HipCirclePoly(c) for c in outs]
+
+
+class HipCircleEvaluation:
+    """CircleEvaluation<HipBackend, M31, BitReversedOrder> (poly/circle/evaluation.ts:98-177)."""
+
+    def __init__(self, domain: CircleDomain, values):
+        self.domain = domain
+        self.values = values if isinstance(values, HipColumn) else HipColumn(values)
+        if self.values.len() != domain.size():
+            raise ValueError("evaluation length does not match the domain size")
+
+    new = staticmethod(lambda domain, values: HipCircleEvaluation(domain, values))
+
+    @staticmethod
+    def precomputeTwiddles(coset): return precompute_twiddles(coset)
+    @staticmethod
+    def to_cpu(values: HipColumn): return values.toCpu()
+    @staticmethod
+    def bitReverseColumn(col: HipColumn): HipBackend().bitReverseColumn(col)
+
+    def interpolate(self) -> HipCirclePoly:
+        return HipCirclePoly.interpolate(self, precompute_twiddles(self.domain.halfCoset))
+
+    def interpolateWithTwiddles(self, twiddles) -> HipCirclePoly: return HipCirclePoly.interpolate(self, twiddles)
+    def toCpu(self): return self.values.toCpu()
+
+    def bitReverse(self) -> "HipCircleEvaluation":
+        out = self.values.clone()
+        HipBackend().bitReverseColumn(out)
+        return HipCircleEvaluation(self.domain, out)
+
+
+class SecureEvaluation:
+    """SecureEvaluation<HipBackend, BitReversedOrder> (poly/circle/secure_poly.ts:46-81): 4 coordinate columns."""
+
+    def __init__(self, domain: CircleDomain, values: SecureColumnByCoords):
+        if values.len() != domain.size():
+            raise ValueError("evaluation length does not match the domain size")
+        self.domain, self.values = domain, values
+
+    def len(self): return self.values.len()
+
+    def interpolateWithTwiddles(self, twiddles) -> list:
+        """SecureCirclePoly = 4 coordinate polys (secure_poly.ts:73-80)."""
+        return interpolate_columns([HipCircleEvaluation(self.domain, c) for c in self.values.columns], twiddles)
+
+
+class LineEvaluation:
+    """LineEvaluation<HipBackend> (poly/line.ts:241-329): QM31 evaluations on a LineDomain, bit-reversed order."""
+
+    def __init__(self, domain: LineDomain, values: SecureColumnByCoords):
+        if values.len() != domain.size():
+            raise ValueError("evaluation length does not match the domain size")
+        self._domain, self.values = domain, values
+
+    new = staticmethod(lambda domain, values: LineEvaluation(domain, values))
+
+    @staticmethod
+    def new_zero(domain: LineDomain): return LineEvaluation(domain, SecureColumnByCoords.zeros(domain.size()))
+    def domain(self): return self._domain
+    def len(self): return self.values.len()
