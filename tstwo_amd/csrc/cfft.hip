@@ -23,15 +23,17 @@
 // traffic: 8 per element per pass (+ <= 2 for twiddles).  DESIGN.md §CFFT has the roofline numbers.
 #include "common.h"
 #include "host_field.h"
+#include <stdlib.h>
 
 using namespace tstwo;
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr u32 kMaxLogTileB = 13;   // contiguous (bottom) tile: 2^13 words = 32 KiB + pad
-constexpr u32 kLogTileA = 14;      // strided tile: 2^k rows x 2^(14-k) words = 64 KiB + pad
+constexpr u32 kMaxLogTileB = 13;   // contiguous (bottom) tile: 2^13 words = 32 KiB + pad, 256 lanes
+constexpr u32 kLogTileA = 14;      // strided tile: 2^k rows x 2^(14-k) words = 64 KiB + pad, 512 lanes
 constexpr u32 kMaxKA = 9;          // at most 9 layers per strided pass (rows of >= 32 words = 128 B)
+constexpr int kThreadsB = 256, kThreadsA = 512;
+constexpr int kMaxV4 = 8;          // 16-byte vectors per lane per tile (32 words)
 
 struct PassParams {
     u32 n;        // log size of the column
@@ -40,58 +42,77 @@ struct PassParams {
     u32 c;        // log2(words per row); 0 for the bottom pass (lo == 0, one contiguous row)
     u32 logt;     // c + k = log2(tile words)
     u32 scale;    // interpolate's 2^-n, applied by the last pass; 0 = no scaling
+    u32 cols_per_wg;
     const u32 *tw_end;  // tree + L
 };
 
 __device__ __forceinline__ u32 phys(u32 e) { return e + (e >> 5); }
 
-// One register stage: G consecutive layers on LDS bits [q, q+G).
+// x * t for a twiddle stored doubled (t2 = 2t < 2^32): the 64-bit product's high word is
+// floor(x t / 2^31) and its low word >> 1 is (x t) mod 2^31, so the Mersenne fold needs no
+// and/alignbit (stwo's SIMD backend keeps "dbl" twiddles for the same reason).
+__device__ __forceinline__ u32 m31_mul_dbl(u32 x, u32 t2) {
+    u64 p = (u64)x * (u64)t2;
+    u32 s = (u32)(p >> 32) + ((u32)p >> 1);
+    return min(s, s - M31_P);
+}
+__device__ __forceinline__ void bf_dbl(u32 &v0, u32 &v1, u32 t2) {
+    u32 m = m31_mul_dbl(v1, t2);
+    u32 a = m31_add(v0, m);
+    v1 = m31_sub(v0, m);
+    v0 = a;
+}
+__device__ __forceinline__ void ibf_dbl(u32 &v0, u32 &v1, u32 t2) {
+    u32 a = m31_add(v0, v1);
+    v1 = m31_mul_dbl(m31_sub(v0, v1), t2);
+    v0 = a;
+}
+
+// Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits vmcnt(0), which would
+// serialise the in-flight prefetch loads / tile stores behind every stage (guide §5 "Pipelining across
+// barriers"); global memory is never shared between lanes inside these kernels, so LDS ordering suffices.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+}  // namespace
+#include "cfft_fast.cuh"
+namespace {
+
+// One register stage: G consecutive layers on LDS bits [q, q+G).  Twiddles come from the tile's LDS
+// heap `twl` (doubled values): layer bit b lives at twl[2^(logt-1-b) + (e >> (b+1))].
 // CIRCLE: bit 0 of this stage is the circle layer (only when q == 0 and lo == 0; needs G >= 3).
-template <int G, bool INV, bool CIRCLE>
-__device__ __forceinline__ void run_stage(u32 *lds, const u32 q, const PassParams &pp, const u32 hi) {
-    const u32 ngroups = 1u << (pp.logt - G);
-    for (u32 gid = threadIdx.x; gid < ngroups; gid += kThreads) {
+template <int G, bool INV, bool CIRCLE, int THREADS>
+__device__ __forceinline__ void run_stage(u32 *lds, const u32 *twl, const u32 q, const u32 logt) {
+    const u32 ngroups = 1u << (logt - G);
+    for (u32 gid = threadIdx.x; gid < ngroups; gid += THREADS) {
         const u32 low = gid & ((1u << q) - 1u), high = gid >> q;
         const u32 e0 = (high << (q + G)) | low;
         u32 v[1 << G];
 #pragma unroll
         for (int m = 0; m < (1 << G); m++) v[m] = lds[phys(e0 + ((u32)m << q))];
-
-        u32 tw1[(G >= 2) ? (1 << (G - 2)) : 1];   // layer-1 twiddles of the group, shared with the circle layer
-        (void)tw1;
 #pragma unroll
         for (int step = 0; step < G; step++) {
             const int l = INV ? step : (G - 1 - step);
             const u32 b = q + (u32)l;                       // LDS bit of this layer
             if (CIRCLE && l == 0) {
-                if (INV) {                                  // inverse runs the circle layer first: fetch tw1 now
-                    const u32 *seg1 = pp.tw_end - (1u << (pp.n - 1));
-                    const u32 hb1 = (hi << (pp.logt - 2)) | (high << (G - 2));
-#pragma unroll
-                    for (int j = 0; j < (1 << (G - 2)); j++) tw1[j] = seg1[hb1 + j];
-                }
+                // tw(0,h) = +-tw(1,(h>>1)^1), negative iff (h ^ (h>>1)) & 1   (backend/cpu/circle.ts:270-278)
+                const u32 *t1 = twl + (1u << (logt - 2)) + (high << (G - 2));
 #pragma unroll
                 for (int j = 0; j < (1 << (G - 1)); j++) {
-                    u32 t = tw1[(j >> 1) ^ 1];
-                    if ((j ^ (j >> 1)) & 1) t = m31_neg(t);
-                    if (INV) m31_ibutterfly(v[2 * j], v[2 * j + 1], t);
-                    else m31_butterfly(v[2 * j], v[2 * j + 1], t);
+                    u32 t2 = t1[(j >> 1) ^ 1];
+                    if ((j ^ (j >> 1)) & 1) t2 = 0xFFFFFFFEu - t2;      // 2(P - t)
+                    if (INV) ibf_dbl(v[2 * j], v[2 * j + 1], t2);
+                    else bf_dbl(v[2 * j], v[2 * j + 1], t2);
                 }
             } else {
-                const u32 i = pp.lo + (b - pp.c);           // global layer
-                const u32 *seg = pp.tw_end - (1u << (pp.n - i));
-                const u32 hb = (hi << (pp.logt - 1 - b)) | (high << (G - 1 - l));
+                const u32 *tl = twl + (1u << (logt - 1 - b)) + (high << (G - 1 - l));
 #pragma unroll
                 for (int j = 0; j < (1 << (G - 1 - l)); j++) {
-                    u32 t;
-                    if (CIRCLE && l == 1 && INV) t = tw1[j];
-                    else t = seg[hb + j];
-                    if (CIRCLE && l == 1 && !INV) tw1[j] = t;
+                    const u32 t2 = tl[j];
 #pragma unroll
                     for (int r = 0; r < (1 << l); r++) {
                         const int m0 = (j << (l + 1)) | r;
-                        if (INV) m31_ibutterfly(v[m0], v[m0 + (1 << l)], t);
-                        else m31_butterfly(v[m0], v[m0 + (1 << l)], t);
+                        if (INV) ibf_dbl(v[m0], v[m0 + (1 << l)], t2);
+                        else bf_dbl(v[m0], v[m0 + (1 << l)], t2);
                     }
                 }
             }
@@ -101,14 +122,14 @@ __device__ __forceinline__ void run_stage(u32 *lds, const u32 q, const PassParam
     }
 }
 
-template <bool INV, bool CIRCLE>
-__device__ __forceinline__ void dispatch_stage(int g, u32 *lds, u32 q, const PassParams &pp, u32 hi) {
+template <bool INV, bool CIRCLE, int THREADS>
+__device__ __forceinline__ void dispatch_stage(int g, u32 *lds, const u32 *twl, u32 q, u32 logt) {
     switch (g) {
-        case 5: run_stage<5, INV, CIRCLE>(lds, q, pp, hi); break;
-        case 4: run_stage<4, INV, CIRCLE>(lds, q, pp, hi); break;
-        case 3: run_stage<3, INV, CIRCLE>(lds, q, pp, hi); break;
-        case 2: if (!CIRCLE) run_stage<2, INV, false>(lds, q, pp, hi); break;
-        case 1: if (!CIRCLE) run_stage<1, INV, false>(lds, q, pp, hi); break;
+        case 5: run_stage<5, INV, CIRCLE, THREADS>(lds, twl, q, logt); break;
+        case 4: run_stage<4, INV, CIRCLE, THREADS>(lds, twl, q, logt); break;
+        case 3: run_stage<3, INV, CIRCLE, THREADS>(lds, twl, q, logt); break;
+        case 2: if (!CIRCLE) run_stage<2, INV, false, THREADS>(lds, twl, q, logt); break;
+        case 1: if (!CIRCLE) run_stage<1, INV, false, THREADS>(lds, twl, q, logt); break;
         default: break;
     }
 }
@@ -132,62 +153,108 @@ __device__ __forceinline__ int plan_stages(const PassParams &pp, int *g_out) {
     return cnt;
 }
 
-template <bool INV>
-__global__ void __launch_bounds__(kThreads) k_cfft_pass(ColPtrs cols, u32 n_cols, PassParams pp) {
+// One workgroup = one tile position x `cols_per_wg` columns.  The tile's twiddles are staged once
+// in LDS and reused for every column; the next column's tile is prefetched into registers while
+// the current one is transformed, so HBM latency overlaps the butterflies inside the workgroup.
+template <bool INV, int THREADS>
+__global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass(ColPtrs cols, u32 n_cols, PassParams pp) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    // column is the fastest-varying block coordinate: blocks sharing a tile (hence twiddles) are adjacent
-    const u32 col = blockIdx.x % n_cols;
-    const u32 tile = blockIdx.x / n_cols;
-    u32 *__restrict__ data = cols.p[col];
+    const u32 tile_words = 1u << pp.logt;
+    u32 *twl = lds + ((tile_words + (tile_words >> 5) + 3u) & ~3u);     // twiddle heap behind the padded tile
+
+    // column group is the fastest-varying block coordinate: blocks sharing a tile (hence twiddles) are adjacent
+    const u32 groups = (n_cols + pp.cols_per_wg - 1) / pp.cols_per_wg;
+    const u32 cgroup = blockIdx.x % groups;
+    const u32 tile = blockIdx.x / groups;
+    const u32 col0 = cgroup * pp.cols_per_wg;
+    const u32 col1 = min(col0 + pp.cols_per_wg, n_cols);
 
     const u32 mid_bits = pp.lo - pp.c;                     // 0 for the bottom pass
     const u32 mid = tile & ((1u << mid_bits) - 1u);
     const u32 hi = tile >> mid_bits;
     const size_t base = ((size_t)hi << (pp.lo + pp.k)) | ((size_t)mid << pp.c);
-    const u32 tile_words = 1u << pp.logt;
     const u32 cmask = (1u << pp.c) - 1u;
 
-    // ---- global -> LDS, 16 bytes per lane
-    if (pp.logt >= 2) {
-        for (u32 e = 4u * threadIdx.x; e < tile_words; e += 4u * kThreads) {
-            const size_t g = base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask);
-            const uint4 x = *reinterpret_cast<const uint4 *>(data + g);
-            const u32 p = phys(e);
-            lds[p] = x.x; lds[p + 1] = x.y; lds[p + 2] = x.z; lds[p + 3] = x.w;
+    // ---- prefetch the first column's tile (16 bytes per lane per access)
+    uint4 pf[kMaxV4];
+    {
+        const u32 *__restrict__ data = cols.p[col0];
+#pragma unroll
+        for (int it = 0; it < kMaxV4; it++) {
+            const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
+            if (e < tile_words) pf[it] = *reinterpret_cast<const uint4 *>(data + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask));
         }
     }
-    __syncthreads();
+    // ---- twiddle heap: level lv (2^lv entries at twl[2^lv ..]) holds layer bit b = logt-1-lv, i.e. global
+    //      layer i = lo + b - c, entries tree[L - 2^(n-i) + (hi << lv) + hl]; stored doubled.
+    {
+        const u32 skip = (pp.lo == 0) ? 1u : 0u;            // the circle layer has no entries of its own
+        const u32 heap = 1u << (pp.k - skip);
+        for (u32 idx = threadIdx.x + 1; idx < heap; idx += THREADS) {
+            const u32 lv = 31u - (u32)__clz(idx);
+            const u32 b = pp.logt - 1u - lv;
+            const u32 i = pp.lo + b - pp.c;
+            const u32 t = pp.tw_end[-(ptrdiff_t)(1u << (pp.n - i)) + (ptrdiff_t)((hi << lv) + (idx - (1u << lv)))];
+            twl[idx] = t + t;
+        }
+    }
 
     int gs[8];
     const int n_stages = plan_stages(pp, gs);
-    if (!INV) {
-        u32 q = pp.logt;
-        for (int s = n_stages - 1; s >= 0; s--) {
-            q -= (u32)gs[s];
-            if (pp.lo == 0 && q == 0) dispatch_stage<false, true>(gs[s], lds, q, pp, hi);
-            else dispatch_stage<false, false>(gs[s], lds, q, pp, hi);
-            __syncthreads();
-        }
-    } else {
-        u32 q = pp.c;
-        for (int s = 0; s < n_stages; s++) {
-            if (pp.lo == 0 && q == 0) dispatch_stage<true, true>(gs[s], lds, q, pp, hi);
-            else dispatch_stage<true, false>(gs[s], lds, q, pp, hi);
-            q += (u32)gs[s];
-            __syncthreads();
-        }
-    }
 
-    // ---- LDS -> global (fused 2^-n scaling on interpolate's last pass)
-    for (u32 e = 4u * threadIdx.x; e < tile_words; e += 4u * kThreads) {
-        const size_t g = base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask);
-        const u32 p = phys(e);
-        uint4 x = make_uint4(lds[p], lds[p + 1], lds[p + 2], lds[p + 3]);
-        if (INV && pp.scale) {
-            x.x = m31_mul(x.x, pp.scale); x.y = m31_mul(x.y, pp.scale);
-            x.z = m31_mul(x.z, pp.scale); x.w = m31_mul(x.w, pp.scale);
+    for (u32 col = col0; col < col1; col++) {
+        // ---- registers -> LDS
+#pragma unroll
+        for (int it = 0; it < kMaxV4; it++) {
+            const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
+            if (e < tile_words) {
+                const u32 p = phys(e);
+                lds[p] = pf[it].x; lds[p + 1] = pf[it].y; lds[p + 2] = pf[it].z; lds[p + 3] = pf[it].w;
+            }
         }
-        *reinterpret_cast<uint4 *>(data + g) = x;
+        __syncthreads();
+        // ---- prefetch the next column while this one is transformed
+        if (col + 1 < col1) {
+            const u32 *__restrict__ next = cols.p[col + 1];
+#pragma unroll
+            for (int it = 0; it < kMaxV4; it++) {
+                const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
+                if (e < tile_words) pf[it] = *reinterpret_cast<const uint4 *>(next + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask));
+            }
+        }
+        if (!INV) {
+            u32 q = pp.logt;
+            for (int s = n_stages - 1; s >= 0; s--) {
+                q -= (u32)gs[s];
+                if (pp.lo == 0 && q == 0) dispatch_stage<false, true, THREADS>(gs[s], lds, twl, q, pp.logt);
+                else dispatch_stage<false, false, THREADS>(gs[s], lds, twl, q, pp.logt);
+                __syncthreads();
+            }
+        } else {
+            u32 q = pp.c;
+            for (int s = 0; s < n_stages; s++) {
+                if (pp.lo == 0 && q == 0) dispatch_stage<true, true, THREADS>(gs[s], lds, twl, q, pp.logt);
+                else dispatch_stage<true, false, THREADS>(gs[s], lds, twl, q, pp.logt);
+                q += (u32)gs[s];
+                __syncthreads();
+            }
+        }
+        // ---- LDS -> global (fused 2^-n scaling on interpolate's last pass)
+        u32 *__restrict__ data = cols.p[col];
+#pragma unroll
+        for (int it = 0; it < kMaxV4; it++) {
+            const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
+            if (e < tile_words) {
+                const u32 p = phys(e);
+                uint4 x = make_uint4(lds[p], lds[p + 1], lds[p + 2], lds[p + 3]);
+                if (INV && pp.scale) {
+                    x.x = m31_mul(x.x, pp.scale); x.y = m31_mul(x.y, pp.scale);
+                    x.z = m31_mul(x.z, pp.scale); x.w = m31_mul(x.w, pp.scale);
+                }
+                *reinterpret_cast<uint4 *>(data + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask)) = x;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -239,32 +306,103 @@ int plan_passes(u32 n, Pass *out) {
     return cnt;
 }
 
-template <bool INV>
-int launch_pass(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u32 *tw, u32 tw_log, u32 scale) {
+template <bool INV, int THREADS>
+int launch_pass_t(u32 *const *cols, size_t n_cols, const PassParams &pp0) {
     Context &c = ctx();
-    PassParams pp;
-    pp.n = n; pp.lo = ps.lo; pp.k = ps.k; pp.c = ps.c; pp.logt = ps.c + ps.k; pp.scale = scale;
-    pp.tw_end = tw + ((size_t)1 << tw_log);
-    size_t tiles = (size_t)1 << (n - pp.logt);
-    size_t lds_bytes = (((size_t)1 << pp.logt) + (((size_t)1 << pp.logt) >> 5) + 4) * sizeof(u32);
+    PassParams pp = pp0;
+    const size_t tile_words = (size_t)1 << pp.logt;
+    const size_t heap_words = (size_t)1 << (pp.k - (pp.lo == 0 ? 1 : 0));
+    const size_t lds_bytes = (((tile_words + (tile_words >> 5) + 3) & ~(size_t)3) + heap_words + 4) * sizeof(u32);
     static bool lds_attr_set = false;   // tiles above 64 KiB need the opt-in (160 KiB LDS per CU on gfx950)
     if (!lds_attr_set) {
-        TSTWO_HIP(hipFuncSetAttribute((const void *)k_cfft_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        TSTWO_HIP(hipFuncSetAttribute((const void *)k_cfft_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TSTWO_HIP(hipFuncSetAttribute((const void *)k_cfft_pass<INV, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
-    for (size_t i = 0; i < n_cols; i++)
-        if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
+    const size_t tiles = (size_t)1 << (pp.n - pp.logt);
     for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
         size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
         ColPtrs cp;
         for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[b0 + i];
-        size_t blocks = tiles * cnt;
+        // columns per workgroup: amortise the twiddle staging, but keep >= ~6 workgroups per CU in the grid
+        u32 cpw = 4;
+        while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)c.n_cus * 6) cpw >>= 1;
+        if (cpw > cnt) cpw = (u32)cnt;
+        pp.cols_per_wg = cpw;
+        size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
         if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
-        hipLaunchKernelGGL(k_cfft_pass<INV>, dim3((unsigned)blocks), dim3(kThreads), lds_bytes, c.stream, cp, (u32)cnt, pp);
+        hipLaunchKernelGGL((k_cfft_pass<INV, THREADS>), dim3((unsigned)blocks), dim3(THREADS), lds_bytes, c.stream, cp, (u32)cnt, pp);
     }
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
+}
+
+template <bool INV>
+int launch_pass(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u32 *tw, u32 tw_log, u32 scale) {
+    PassParams pp;
+    pp.n = n; pp.lo = ps.lo; pp.k = ps.k; pp.c = ps.c; pp.logt = ps.c + ps.k; pp.scale = scale; pp.cols_per_wg = 1;
+    pp.tw_end = tw + ((size_t)1 << tw_log);
+    for (size_t i = 0; i < n_cols; i++)
+        if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
+    if (ps.lo == 0) return launch_pass_t<INV, kThreadsB>(cols, n_cols, pp);
+    return launch_pass_t<INV, kThreadsA>(cols, n_cols, pp);
+}
+
+u32 pick_cols_per_wg(size_t tiles, size_t cnt) {
+    // columns per workgroup: amortise the twiddle staging, but keep >= ~8 workgroups per CU in the grid
+    u32 cpw = 4;
+    while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)ctx().n_cus * 8) cpw >>= 1;
+    if (cpw > cnt) cpw = (u32)cnt;
+    return cpw;
+}
+
+template <typename KernelT, typename... Args>
+int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t tiles, u32 *const *cols, size_t n_cols, Args... args) {
+    Context &c = ctx();
+    TSTWO_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (getenv("TSTWO_CFFT_TRACE")) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, (const void *)kernel);
+        fprintf(stderr, "[cfft] kernel %p threads %d lds %zu: getattr=%d maxDynamicSharedSizeBytes=%d sharedSizeBytes=%zu numRegs=%d maxThreadsPerBlock=%d\n",
+                (const void *)kernel, threads, lds_bytes, (int)e, fa.maxDynamicSharedSizeBytes, fa.sharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock);
+    }
+    for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
+        size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+        ColPtrs cp;
+        for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[b0 + i];
+        const u32 cpw = pick_cols_per_wg(tiles, cnt);
+        size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
+        if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds_bytes, c.stream, cp, (u32)cnt, cpw, args...);
+    }
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+template <bool INV, int K>
+int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, u32 scale) {
+    const size_t tiles = (size_t)1 << (n - 14);
+    return launch_fast_kernel(fast::k_cfft_a<INV, K>, 1024, ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols,
+                              n, lo, tw_end, scale);
+}
+
+template <bool INV>
+int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u32 *tw_end, u32 scale) {
+    if (ps.lo == 0) {
+        const size_t tiles = (size_t)1 << (n - 13);
+        return launch_fast_kernel(fast::k_cfft_b13<INV>, 512, ((size_t)(1 << 13) + (1 << 8) + 512) * sizeof(u32), tiles, cols, n_cols, n, tw_end, scale);
+    }
+    switch (ps.k) {
+        case 1: return launch_a<INV, 1>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 2: return launch_a<INV, 2>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 3: return launch_a<INV, 3>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 4: return launch_a<INV, 4>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 5: return launch_a<INV, 5>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 6: return launch_a<INV, 6>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 7: return launch_a<INV, 7>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 8: return launch_a<INV, 8>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 9: return launch_a<INV, 9>(cols, n_cols, n, ps.lo, tw_end, scale);
+        default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+    }
 }
 
 template <bool INV>
@@ -299,14 +437,27 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     if (tw_log > 31 || ((size_t)1 << (n - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     Pass passes[8];
     int np = plan_passes(n, passes);
+    for (size_t i = 0; i < n_cols; i++)
+        if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
+    if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
+    const u32 *tw_end = tw + ((size_t)1 << tw_log);
+    const bool fast_path = n >= kMaxLogTileB && n <= 28;
+    const char *dbg_env = getenv("TSTWO_CFFT_GENERIC");      // debugging aid: 1 = generic kernel for the bottom pass, 2 = for strided passes
+    const int dbg_generic = dbg_env ? atoi(dbg_env) : 0;      // specialised kernels (cfft_fast.cuh); smaller sizes use the generic one
     if (!INV) {
         for (int s = np - 1; s >= 0; s--) {
-            int rc = launch_pass<false>(cols, n_cols, n, passes[s], tw, tw_log, 0);
+            if ((dbg_generic & 4) && passes[s].lo == 0) continue;
+            const bool f = fast_path && !(dbg_generic & (passes[s].lo == 0 ? 1 : 2));
+            int rc = f ? launch_fast<false>(cols, n_cols, n, passes[s], tw_end, 0)
+                               : launch_pass<false>(cols, n_cols, n, passes[s], tw, tw_log, 0);
             if (rc) return rc;
         }
     } else {
         for (int s = 0; s < np; s++) {
-            int rc = launch_pass<true>(cols, n_cols, n, passes[s], tw, tw_log, s == np - 1 ? n_inv : 0);
+            const u32 sc = s == np - 1 ? n_inv : 0;
+            const bool f = fast_path && !(dbg_generic & (passes[s].lo == 0 ? 1 : 2));
+            int rc = f ? launch_fast<true>(cols, n_cols, n, passes[s], tw_end, sc)
+                               : launch_pass<true>(cols, n_cols, n, passes[s], tw, tw_log, sc);
             if (rc) return rc;
         }
     }

@@ -1,0 +1,372 @@
+// cfft_fast.cuh — the specialised Circle-FFT pass kernels used for log_size >= 13 (included by cfft.hip).
+//
+// Geometry is compile-time so that addressing folds into immediates and the register budget stays
+// near 64 VGPRs (8 waves/SIMD): every lane owns 16 words of the tile.
+//   k_cfft_b13<INV>     bottom pass: layers 0..12 on a contiguous 2^13-word tile, 512 lanes.
+//   k_cfft_a<INV, K>    strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^(14-K) words, 1024 lanes.
+// Structure of one tile (forward; the inverse mirrors it):
+//   1. the tile arrives as four 16-byte loads per lane a quarter-tile apart, so the pass's two top layers
+//      are a radix-4 butterfly in registers before anything touches LDS;
+//   2. the middle layers run as LDS radix-8/16 stages (compile-time strides, twiddles from a small LDS heap
+//      that is staged once per workgroup and reused for every column the workgroup owns);
+//   3. the last stage leaves each lane with its final 16 words and stores them straight to HBM.
+//   The next column's tile is prefetched into registers while the current one is transformed; barriers
+//   drain LDS only (lds_barrier), so global loads/stores stay in flight across them.
+// LDS layout: word e lives at e + (e >> 5) (one pad word per 32).  Every access pattern used here maps the
+// 32 lanes of a half-wave onto 32 distinct banks (4-word runs at lane stride 4, 16-word runs at lane stride
+// 16, unit-stride runs for stage bits >= 5; the bit-4 stage assigns groups to lanes with bits 4/5 of the
+// lane id swapped), and the address of word e0 + (m << Q) of a register group is pad(e0) + constant(m), so
+// one address register and immediate offsets serve a whole group.
+#pragma once
+
+namespace fast {
+
+__device__ __forceinline__ u32 pad(u32 e) { return e + (e >> 5); }
+// offset of word (m << Q) relative to pad(e0) when e0 has zeros in the group's bit range (no carries: see DESIGN.md)
+template <int Q>
+__device__ __forceinline__ constexpr u32 off(int m) { return ((u32)m << Q) + (((u32)m << Q) >> 5); }
+
+template <bool INV>
+__device__ __forceinline__ void bfly(u32 &a, u32 &b, u32 t2) {
+    if (INV) ibf_dbl(a, b, t2);
+    else bf_dbl(a, b, t2);
+}
+
+// G layers on LDS bits [Q, Q+G) of a 2^G-word register group; twiddles from the heap:
+// layer bit b lives at twl[2^(LOGT-1-b) + (e >> (b+1))].
+template <int G, int Q, int LOGT, bool INV>
+__device__ __forceinline__ void group_layers(u32 (&v)[1 << G], const u32 *twl, const u32 high) {
+#pragma unroll
+    for (int step = 0; step < G; step++) {
+        const int l = INV ? step : (G - 1 - step);
+        const u32 *tl = twl + (1u << (LOGT - 1 - (Q + l))) + (high << (G - 1 - l));
+#pragma unroll
+        for (int j = 0; j < (1 << (G - 1 - l)); j++) {
+            const u32 t2 = tl[j];
+#pragma unroll
+            for (int r = 0; r < (1 << l); r++) {
+                const int m0 = (j << (l + 1)) | r;
+                bfly<INV>(v[m0], v[m0 + (1 << l)], t2);
+            }
+        }
+    }
+}
+
+// In-place LDS stage: every lane handles 16 >> G groups of 2^G words.
+template <int G, int Q, int LOGT, int THREADS, bool INV>
+__device__ __forceinline__ void lds_stage(u32 *lds, const u32 *twl) {
+#pragma unroll
+    for (int g = 0; g < (16 >> G); g++) {
+        u32 gid = threadIdx.x + (u32)g * THREADS;
+        if (Q == 4) gid = (gid & ~0x30u) | ((gid & 0x10u) << 1) | ((gid & 0x20u) >> 1);   // bank-conflict-free lane -> group map
+        const u32 low = gid & ((1u << Q) - 1u), high = gid >> Q;
+        u32 *p = lds + pad((high << (Q + G)) | low);
+        u32 v[1 << G];
+#pragma unroll
+        for (int m = 0; m < (1 << G); m++) v[m] = p[off<Q>(m)];
+        group_layers<G, Q, LOGT, INV>(v, twl, high);
+#pragma unroll
+        for (int m = 0; m < (1 << G); m++) p[off<Q>(m)] = v[m];
+    }
+}
+
+// The pass's two top layers on the four quarter-tile vectors of a lane (component-wise radix-4).
+// x[j], j = (top bit, second bit).  ta: top-layer twiddle; tb0/tb1: second-layer twiddles of the two halves.
+template <bool INV, bool TWO>
+__device__ __forceinline__ void top_layers(uint4 (&x)[4], u32 ta, u32 tb0, u32 tb1) {
+    u32 *p0 = reinterpret_cast<u32 *>(&x[0]), *p1 = reinterpret_cast<u32 *>(&x[1]);
+    u32 *p2 = reinterpret_cast<u32 *>(&x[2]), *p3 = reinterpret_cast<u32 *>(&x[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        u32 a = p0[k], b = p1[k], c = p2[k], d = p3[k];
+        if (!INV) {
+            bfly<false>(a, c, ta); bfly<false>(b, d, ta);
+            if (TWO) { bfly<false>(a, b, tb0); bfly<false>(c, d, tb1); }
+        } else {
+            if (TWO) { bfly<true>(a, b, tb0); bfly<true>(c, d, tb1); }
+            bfly<true>(a, c, ta); bfly<true>(b, d, ta);
+        }
+        p0[k] = a; p1[k] = b; p2[k] = c; p3[k] = d;
+    }
+}
+
+__device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
+    return make_uint4(m31_mul(x.x, s), m31_mul(x.y, s), m31_mul(x.z, s), m31_mul(x.w, s));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bottom pass: layers 0..12 (circle layer included) of a contiguous 2^13-word tile.
+template <bool INV>
+__global__ void __launch_bounds__(512) k_cfft_b13(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
+                                                 const u32 *__restrict__ tw_end, u32 scale) {
+    constexpr int LOGT = 13, THREADS = 512;
+    constexpr u32 T = 1u << LOGT, QT = T / 4;
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    u32 *twl = lds + T + T / 32;                          // 512-entry heap: layer bits 4..10
+    const u32 t = threadIdx.x;
+    const u32 groups = (n_cols + cols_per_wg - 1) / cols_per_wg;
+    const u32 hi = blockIdx.x / groups;                   // tile index
+    const u32 col0 = (blockIdx.x % groups) * cols_per_wg;
+    const u32 col1 = min(col0 + cols_per_wg, n_cols);
+    const size_t base = (size_t)hi << LOGT;
+
+    // twiddles of this lane's 16-word run for layers 1..3 (registers, doubled); layer 0 reuses layer 1's
+    u32 t1[4], t2[2], t3;
+    {
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << 11) + 4 * t);
+        const uint2 q2 = *reinterpret_cast<const uint2 *>(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << 10) + 2 * t);
+        const u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << 9) + t)];
+        t1[0] = q1.x + q1.x; t1[1] = q1.y + q1.y; t1[2] = q1.z + q1.z; t1[3] = q1.w + q1.w;
+        t2[0] = q2.x + q2.x; t2[1] = q2.y + q2.y;
+        t3 = q3 + q3;
+    }
+    // heap: level lv in 2..8 holds layer bit b = 12 - lv
+    if (t >= 4) {
+        const u32 lv = 31u - (u32)__clz(t);
+        const u32 b = 12u - lv;
+        const u32 v = tw_end[-(ptrdiff_t)((size_t)1 << (n - b)) + (ptrdiff_t)(((size_t)hi << lv) + (t - (1u << lv)))];
+        twl[t] = v + v;
+    }
+    u32 ta, tb0, tb1;                                      // layer 12 / layer 11 twiddles (wave-uniform)
+    {
+        const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - 12)) + (ptrdiff_t)hi];
+        const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 11)) + (ptrdiff_t)(2 * (size_t)hi)];
+        const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 11)) + (ptrdiff_t)(2 * (size_t)hi + 1)];
+        ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
+    }
+
+    uint4 pf[4];
+    {
+        const u32 *__restrict__ d = cols.p[col0] + base;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            pf[j] = *reinterpret_cast<const uint4 *>(d + (INV ? 16 * t + 4 * j : 4 * t + j * QT));
+    }
+    for (u32 col = col0; col < col1; col++) {
+        u32 *__restrict__ data = cols.p[col] + base;
+        const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+        if (!INV) {
+            top_layers<false, true>(pf, ta, tb0, tb1);                    // layers 12, 11
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
+                p[0] = pf[j].x; p[1] = pf[j].y; p[2] = pf[j].z; p[3] = pf[j].w;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + 4 * t + j * QT);
+            lds_stage<3, 8, LOGT, THREADS, false>(lds, twl);               // layers 10..8
+            lds_barrier();
+            lds_stage<4, 4, LOGT, THREADS, false>(lds, twl);               // layers 7..4
+            lds_barrier();
+            u32 v[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) v[m] = lds[pad(16 * t) + m];
+#pragma unroll
+            for (int m = 0; m < 8; m++) bf_dbl(v[m], v[m + 8], t3);                                  // layer 3
+#pragma unroll
+            for (int m = 0; m < 16; m++) if (!(m & 4)) bf_dbl(v[m], v[m + 4], t2[m >> 3]);           // layer 2
+#pragma unroll
+            for (int m = 0; m < 16; m++) if (!(m & 2)) bf_dbl(v[m], v[m + 2], t1[m >> 2]);           // layer 1
+#pragma unroll
+            for (int j = 0; j < 8; j++) {                                                            // circle layer
+                u32 tc = t1[(j >> 1) ^ 1];
+                if ((j ^ (j >> 1)) & 1) tc = 0xFFFFFFFEu - tc;
+                bf_dbl(v[2 * j], v[2 * j + 1], tc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                *reinterpret_cast<uint4 *>(data + 16 * t + 4 * j) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            lds_barrier();
+        } else {
+            u32 v[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v[4 * j] = pf[j].x; v[4 * j + 1] = pf[j].y; v[4 * j + 2] = pf[j].z; v[4 * j + 3] = pf[j].w; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                u32 tc = t1[(j >> 1) ^ 1];
+                if ((j ^ (j >> 1)) & 1) tc = 0xFFFFFFFEu - tc;
+                ibf_dbl(v[2 * j], v[2 * j + 1], tc);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) if (!(m & 2)) ibf_dbl(v[m], v[m + 2], t1[m >> 2]);
+#pragma unroll
+            for (int m = 0; m < 16; m++) if (!(m & 4)) ibf_dbl(v[m], v[m + 4], t2[m >> 3]);
+#pragma unroll
+            for (int m = 0; m < 8; m++) ibf_dbl(v[m], v[m + 8], t3);
+#pragma unroll
+            for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + 16 * t + 4 * j);
+            lds_stage<4, 4, LOGT, THREADS, true>(lds, twl);
+            lds_barrier();
+            lds_stage<3, 8, LOGT, THREADS, true>(lds, twl);
+            lds_barrier();
+            uint4 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
+                x[j] = make_uint4(p[0], p[1], p[2], p[3]);
+            }
+            top_layers<true, true>(x, ta, tb0, tb1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (scale) x[j] = scale4(x[j], scale);
+                *reinterpret_cast<uint4 *>(data + 4 * t + j * QT) = x[j];
+            }
+            lds_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^C words (C = 14 - K), 1024 lanes.
+template <bool INV, int K>
+__global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n, u32 lo,
+                                                const u32 *__restrict__ tw_end, u32 scale) {
+    constexpr int LOGT = 14, THREADS = 1024, C = LOGT - K;
+    constexpr u32 T = 1u << LOGT, QT = T / 4;
+    constexpr int F = K >= 2 ? 2 : 1;          // layers fused into the load / store
+    constexpr int R = K - F;                   // layers run as LDS stages
+    constexpr int G2 = R > 4 ? 4 : R;          // stage on bits [C, C+G2)
+    constexpr int G1 = R - G2;                 // stage on bits [C+4, C+4+G1)
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    u32 *twl = lds + T + T / 32;               // heap of 2^K entries (levels F..K-1)
+    const u32 t = threadIdx.x;
+    const u32 groups = (n_cols + cols_per_wg - 1) / cols_per_wg;
+    const u32 tile = blockIdx.x / groups;
+    const u32 col0 = (blockIdx.x % groups) * cols_per_wg;
+    const u32 col1 = min(col0 + cols_per_wg, n_cols);
+    const u32 mid_bits = lo - C;
+    const u32 mid = tile & ((1u << mid_bits) - 1u);
+    const u32 hi = tile >> mid_bits;
+    const size_t base = ((size_t)hi << (lo + K)) | ((size_t)mid << C);
+    // tile-relative word offset (fits 32 bits: the launcher only uses this kernel for lo + K <= 28)
+    auto goff = [&](u32 e) -> u32 { return ((e >> C) << lo) + (e & ((1u << C) - 1u)); };
+
+    if constexpr (R > 0) {
+        for (u32 idx = t; idx < (1u << K); idx += THREADS) {
+            if (idx >= (1u << F)) {
+                const u32 lv = 31u - (u32)__clz(idx);
+                const u32 i = lo + (K - 1 - lv);           // b = LOGT-1-lv, i = lo + b - C
+                const u32 v = tw_end[-(ptrdiff_t)((size_t)1 << (n - i)) + (ptrdiff_t)(((size_t)hi << lv) + (idx - (1u << lv)))];
+                twl[idx] = v + v;
+            }
+        }
+    }
+    u32 ta, tb0 = 0, tb1 = 0;
+    {
+        const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 1))) + (ptrdiff_t)hi];
+        ta = a + a;
+        if constexpr (F == 2) {
+            const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
+            const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
+            tb0 = b0 + b0; tb1 = b1 + b1;
+        }
+    }
+    // element offsets of this lane's 16 words in the final-stage layout (R > 0)
+    auto e_final = [&](int g, int m) -> u32 {
+        const u32 gid = t + (u32)g * THREADS;
+        const u32 low = gid & ((1u << C) - 1u), high = gid >> C;
+        return (high << (C + G2)) | ((u32)m << C) | low;
+    };
+
+    if constexpr (!INV || R == 0) {
+        // forward (and the LDS-free case): four quarter-tile vectors per lane
+        uint4 pf[4];
+        {
+            const u32 *__restrict__ d = cols.p[col0] + base;
+#pragma unroll
+            for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(d + goff(4 * t + j * QT));
+        }
+        for (u32 col = col0; col < col1; col++) {
+            u32 *__restrict__ data = cols.p[col] + base;
+            const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+            top_layers<INV, F == 2>(pf, ta, tb0, tb1);
+            if constexpr (R == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint4 x = pf[j];
+                    if (INV && scale) x = scale4(x, scale);
+                    *reinterpret_cast<uint4 *>(data + goff(4 * t + j * QT)) = x;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + goff(4 * t + j * QT));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
+                    p[0] = pf[j].x; p[1] = pf[j].y; p[2] = pf[j].z; p[3] = pf[j].w;
+                }
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + goff(4 * t + j * QT));
+                if constexpr (G1 > 0) {
+                    lds_stage<G1, C + 4, LOGT, THREADS, false>(lds, twl);
+                    lds_barrier();
+                }
+                // final stage: butterflies, then straight to HBM (rows of 2^C words: >= 128 B per half-wave)
+#pragma unroll
+                for (int g = 0; g < (16 >> G2); g++) {
+                    const u32 high = (t + (u32)g * THREADS) >> C;
+                    u32 v[1 << G2];
+#pragma unroll
+                    for (int m = 0; m < (1 << G2); m++) v[m] = lds[pad(e_final(g, 0)) + off<C>(m)];
+                    group_layers<G2, C, LOGT, false>(v, twl, high);
+#pragma unroll
+                    for (int m = 0; m < (1 << G2); m++) data[goff(e_final(g, m))] = v[m];
+                }
+                lds_barrier();
+            }
+        }
+    } else {
+        // inverse with LDS stages: the lane's 16 words arrive in the first-stage layout
+        u32 pfs[16];
+        {
+            const u32 *__restrict__ d = cols.p[col0] + base;
+#pragma unroll
+            for (int g = 0; g < (16 >> G2); g++)
+#pragma unroll
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = d[goff(e_final(g, m))];
+        }
+        for (u32 col = col0; col < col1; col++) {
+            u32 *__restrict__ data = cols.p[col] + base;
+            const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+#pragma unroll
+            for (int g = 0; g < (16 >> G2); g++) {
+                const u32 high = (t + (u32)g * THREADS) >> C;
+                u32 v[1 << G2];
+#pragma unroll
+                for (int m = 0; m < (1 << G2); m++) v[m] = pfs[g * (1 << G2) + m];
+                group_layers<G2, C, LOGT, true>(v, twl, high);
+#pragma unroll
+                for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(g, 0)) + off<C>(m)] = v[m];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int g = 0; g < (16 >> G2); g++)
+#pragma unroll
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = next[goff(e_final(g, m))];
+            if constexpr (G1 > 0) {
+                lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl);
+                lds_barrier();
+            }
+            uint4 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
+                x[j] = make_uint4(p[0], p[1], p[2], p[3]);
+            }
+            top_layers<true, F == 2>(x, ta, tb0, tb1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (scale) x[j] = scale4(x[j], scale);
+                *reinterpret_cast<uint4 *>(data + goff(4 * t + j * QT)) = x[j];
+            }
+            lds_barrier();
+        }
+    }
+}
+
+}  // namespace fast
