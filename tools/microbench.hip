@@ -60,6 +60,36 @@ __global__ void __launch_bounds__(256) k_butterfly(u32 *out, u32 seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+
+#define RATE_KERNEL(NAME, EXPR)                                                                       \
+    __global__ void __launch_bounds__(256) NAME(u32 *out, u32 seed) {                                 \
+        u32 a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 + 11, a5 = a0 + 13, a6 = a0 + 17, a7 = a0 + 19; \
+        const u32 k = seed * 2654435761u;                                                             \
+        for (int i = 0; i < ITERS; i++) {                                                             \
+            a0 = EXPR(a0, a1, k); a1 = EXPR(a1, a2, k); a2 = EXPR(a2, a3, k); a3 = EXPR(a3, a4, k);   \
+            a4 = EXPR(a4, a5, k); a5 = EXPR(a5, a6, k); a6 = EXPR(a6, a7, k); a7 = EXPR(a7, a0, k);   \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;           \
+    }
+#define E_ADD3(x, y, k) ((x) + (y) + (k))
+#define E_XOR(x, y, k) ((x) ^ (y))
+#define E_XOR3(x, y, k) ((x) ^ (y) ^ (k))
+#define E_PERM(x, y, k) __builtin_amdgcn_perm((x), (y), 0x01000302u)
+#define E_LSHLOR(x, y, k) (((x) << 7) | (y))
+#define E_ANDOR(x, y, k) (((x) & (k)) | (y))
+#define E_BFI(x, y, k) (((x) & (k)) | ((y) & ~(k)))
+#define E_MUL24(x, y, k) (((x) & 0xffffffu) * ((y) & 0xffffffu))
+#define E_MULLO(x, y, k) ((x) * (y))
+#define E_MULHI(x, y, k) __umulhi((x), (y))
+#define E_MIN(x, y, k) min((x), (y))
+#define E_LSHR(x, y, k) (((x) >> 3) + (y))
+#define E_ROT16(x, y, k) __builtin_amdgcn_alignbit((x) ^ (y), (x) ^ (y), 16)
+#define E_FMA(x, y, k) __float_as_uint(__builtin_fmaf(__uint_as_float(x), __uint_as_float(y), __uint_as_float(k)))
+RATE_KERNEL(k_add3, E_ADD3) RATE_KERNEL(k_xor, E_XOR) RATE_KERNEL(k_xor3, E_XOR3) RATE_KERNEL(k_perm, E_PERM)
+RATE_KERNEL(k_lshlor, E_LSHLOR) RATE_KERNEL(k_andor, E_ANDOR) RATE_KERNEL(k_bfi, E_BFI) RATE_KERNEL(k_mul24, E_MUL24)
+RATE_KERNEL(k_mullo, E_MULLO) RATE_KERNEL(k_mulhi, E_MULHI) RATE_KERNEL(k_min, E_MIN) RATE_KERNEL(k_lshr_add, E_LSHR)
+RATE_KERNEL(k_xor_rot16, E_ROT16) RATE_KERNEL(k_fma, E_FMA)
+
 __device__ __forceinline__ u32 rotr32(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, r); }
 #define G(a, b, c, d, x, y) do { a = a + b + (x); d = rotr32(d ^ a, 16); c = c + d; b = rotr32(b ^ c, 12); a = a + b + (y); d = rotr32(d ^ a, 8); c = c + d; b = rotr32(b ^ c, 7); } while (0)
 #define ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
@@ -124,6 +154,14 @@ int main() {
     float ms;
     ms = time_ms([&] { hipLaunchKernelGGL(k_add, dim3(blocks), dim3(256), 0, 0, out, 1u); }, 20);
     printf(", \"v_add_u32_Tops\": %.2f", lanes * ITERS * 8 / (ms * 1e-3) / 1e12);
+
+#define RATE(NAME, LABEL, OPS)                                                                        \
+    ms = time_ms([&] { hipLaunchKernelGGL(NAME, dim3(blocks), dim3(256), 0, 0, out, 3u); }, 20);       \
+    printf(", \"" LABEL "\": %.2f", lanes * ITERS * 8 * OPS / (ms * 1e-3) / 1e12);
+    RATE(k_fma, "v_fma_f32_Tops", 1) RATE(k_xor, "v_xor_Tops", 1) RATE(k_min, "v_min_u32_Tops", 1) RATE(k_add3, "v_add3_Tops", 1)
+    RATE(k_xor3, "v_xor3_Tops", 1) RATE(k_perm, "v_perm_Tops", 1) RATE(k_lshlor, "v_lshl_or_Tops", 1) RATE(k_andor, "v_and_or_Tops", 1)
+    RATE(k_bfi, "v_bfi_Tops", 1) RATE(k_mul24, "v_mul_u32_u24_Tops", 1) RATE(k_mullo, "v_mul_lo_u32_Tops", 1) RATE(k_mulhi, "v_mul_hi_u32_Tops", 1)
+    RATE(k_lshr_add, "lshr_then_add_pairs_T", 1) RATE(k_xor_rot16, "xor_then_rot16_pairs_T", 1)
     ms = time_ms([&] { hipLaunchKernelGGL(k_alignbit, dim3(blocks), dim3(256), 0, 0, out, 1u); }, 20);
     printf(", \"v_alignbit_Tops\": %.2f", lanes * ITERS * 8 / (ms * 1e-3) / 1e12);
     ms = time_ms([&] { hipLaunchKernelGGL(k_mad64, dim3(blocks), dim3(256), 0, 0, out, 3u); }, 20);

@@ -62,41 +62,146 @@ struct LayerParams {
     u32 is_final;      // 1: this launch holds the last block (finalise)
 };
 
+// One lane hashes several nodes (grid-stride) and software-pipelines the message: the 16 words of the next
+// 64-byte block are fetched into a second register set while the current block is compressed, so the
+// compression (VALU-bound, ~1k ops) hides the HBM latency.  Loads are never branched around (a per-word
+// branch makes hipcc wait vmcnt(0) per element): out-of-range words read a clamped column and are zeroed
+// by a select.
+template <bool HAS_PREV>
+__device__ __forceinline__ void load_block(u32 (&m)[16], const uint4 *__restrict__ prev, const HashColPtrs &cols,
+                                           const LayerParams &lp, size_t node, u32 w) {
+    if (HAS_PREV && w == 0) {      // wave-uniform
+        const uint4 *c = prev + 4 * node;
+        uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w; m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
+        m[8] = c2.x; m[9] = c2.y; m[10] = c2.z; m[11] = c2.w; m[12] = c3.x; m[13] = c3.y; m[14] = c3.z; m[15] = c3.w;
+    } else if (lp.n_cols == 0) {   // wave-uniform: empty message block
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = 0u;
+    } else {
+        const u32 last = lp.n_cols - 1u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 ci = w + (u32)k - lp.col_word0;                // wave-uniform
+            const u32 v = cols.p[min(ci, last)][node];
+            m[k] = (ci <= last) ? v : 0u;
+        }
+    }
+}
+
 template <bool HAS_PREV>
 __global__ void __launch_bounds__(256) k_merkle_layer(const uint4 *__restrict__ prev, HashColPtrs cols, uint4 *__restrict__ out,
                                                      size_t n_nodes, LayerParams lp) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    u32 h[8];
-    if (lp.load_state) {
-        uint4 a = out[2 * i], b = out[2 * i + 1];
-        h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w;
-    } else {
-        h[0] = IV0 ^ 0x01010020u; h[1] = IV1; h[2] = IV2; h[3] = IV3; h[4] = IV4; h[5] = IV5; h[6] = IV6; h[7] = IV7;
-    }
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 W = lp.total_words;
-    u32 w = lp.w_begin;
-    do {
-        u32 m[16];
-        if (HAS_PREV && w == 0) {
-            uint4 c0 = prev[4 * i], c1 = prev[4 * i + 1], c2 = prev[4 * i + 2], c3 = prev[4 * i + 3];
+    const u32 w_stop = lp.w_end < W ? lp.w_end : W;
+    // wave-uniform trip structure: `rows` nodes per lane (tail lanes clamp their loads and skip their stores),
+    // `nb` 64-byte blocks per node
+    const u32 nb = w_stop > lp.w_begin ? (w_stop - lp.w_begin + 15u) / 16u : 1u;
+    const u32 rows = (u32)((n_nodes + stride - 1) / stride);
+    const u32 total = rows * nb;
+    const size_t last_node = n_nodes - 1;
+
+    u32 ma[16], mb[16], h[8];
+    u32 j = 0, blk = 0;                                   // uniform: row number / block number of the block in flight
+    load_block<HAS_PREV>(ma, prev, cols, lp, min(node0, last_node), lp.w_begin);
+
+#define MERKLE_STEP(CUR, NXT)                                                                                         \
+    {                                                                                                                 \
+        const size_t node = node0 + (size_t)j * stride;                                                               \
+        const size_t nc = min(node, last_node);                                                                       \
+        const u32 wc = lp.w_begin + 16u * blk;                                                                        \
+        if (blk == 0) {                                                                                               \
+            if (lp.load_state) {                                                                                      \
+                uint4 a = out[2 * nc], b = out[2 * nc + 1];                                                           \
+                h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w;       \
+            } else {                                                                                                  \
+                h[0] = IV0 ^ 0x01010020u; h[1] = IV1; h[2] = IV2; h[3] = IV3; h[4] = IV4; h[5] = IV5; h[6] = IV6; h[7] = IV7; \
+            }                                                                                                         \
+        }                                                                                                             \
+        u32 jn = j, bn = blk + 1;                                                                                     \
+        if (bn == nb) { bn = 0; jn = j + 1; }                                                                         \
+        if (it + 1 < total)                                                                                           \
+            load_block<HAS_PREV>(NXT, prev, cols, lp, min(node0 + (size_t)jn * stride, last_node), lp.w_begin + 16u * bn); \
+        const u32 bytes_end = (wc + 16 < W ? wc + 16 : W) * 4u;                                                       \
+        b2s_compress(h, CUR, bytes_end, lp.is_final && (wc + 16 >= W));                                               \
+        if (blk + 1 == nb && node < n_nodes) {                                                                        \
+            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);                                                       \
+            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);                                                   \
+        }                                                                                                             \
+        j = jn; blk = bn;                                                                                             \
+    }
+
+    for (u32 it = 0; it < total; it += 2) {
+        MERKLE_STEP(ma, mb)
+        if (it + 1 < total) {
+            const u32 it_save = it;
+            it = it_save + 1;
+            MERKLE_STEP(mb, ma)
+            it = it_save;
+        }
+    }
+#undef MERKLE_STEP
+}
+
+// Several column-free levels per launch: a workgroup of WG lanes owns 2*WG consecutive nodes of layer `log_child`
+// and produces the WG, WG/2, ... nodes above them (LEVELS levels), exchanging digests through LDS.  Every level is
+// still written to its place in the layers buffer (MerkleProver keeps all layers, vcs/prover.ts:24-29).
+// layers: device buffer in tstwo_merkle_commit's layout (layer k at byte offset 32*(2^k - 1)).
+template <int WG>
+__global__ void __launch_bounds__(WG) k_merkle_up(uint4 *__restrict__ layers, u32 log_child, u32 levels) {
+    __shared__ uint4 sh[WG * 2];                                  // digests of the level just produced (2 x uint4 each)
+    const u32 t = threadIdx.x;
+    const uint4 *__restrict__ child = layers + 2 * (((size_t)1 << log_child) - 1);
+    u32 m[16];
+    u32 active = min((u32)WG, 1u << (log_child - 1));             // parents this workgroup produces at the first level
+    if (t < active) {
+        const size_t node = (size_t)blockIdx.x * WG + t;           // parent index in layer log_child-1
+        const uint4 *c = child + 4 * node;
+        uint4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w; m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
+        m[8] = c2.x; m[9] = c2.y; m[10] = c2.z; m[11] = c2.w; m[12] = c3.x; m[13] = c3.y; m[14] = c3.z; m[15] = c3.w;
+    }
+    for (u32 lv = 1; lv <= levels; lv++) {
+        const u32 log_out = log_child - lv;
+        u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+        if (t < active) {
+            b2s_compress(h, m, 64u, true);
+            uint4 *out = layers + 2 * (((size_t)1 << log_out) - 1) + 2 * ((size_t)blockIdx.x * active + t);
+            out[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            out[1] = make_uint4(h[4], h[5], h[6], h[7]);
+            sh[2 * t] = make_uint4(h[0], h[1], h[2], h[3]);
+            sh[2 * t + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        __syncthreads();
+        active >>= 1;
+        if (lv < levels && t < active) {
+            uint4 c0 = sh[4 * t], c1 = sh[4 * t + 1], c2 = sh[4 * t + 2], c3 = sh[4 * t + 3];
             m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w; m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
             m[8] = c2.x; m[9] = c2.y; m[10] = c2.z; m[11] = c2.w; m[12] = c3.x; m[13] = c3.y; m[14] = c3.z; m[15] = c3.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                u32 wi = w + (u32)k;                 // wave-uniform
-                u32 ci = wi - lp.col_word0;
-                m[k] = (wi < W && ci < lp.n_cols) ? cols.p[ci][i] : 0u;
-            }
         }
-        u32 bytes_end = (w + 16 < W ? w + 16 : W) * 4u;   // t counter after this block
-        bool last = lp.is_final && (w + 16 >= W);
-        b2s_compress(h, m, bytes_end, last);
-        w += 16;
-    } while (w < lp.w_end && w < W);
-    out[2 * i] = make_uint4(h[0], h[1], h[2], h[3]);
-    out[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        __syncthreads();
+    }
+}
+
+// Column-free levels log_child-1 .. log_stop of the tree, a few fused launches instead of one launch per level.
+int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
+    Context &c = ctx();
+    while (log_child > log_stop) {
+        const u32 remaining = log_child - log_stop;
+        const u32 parents_log = log_child - 1;
+        if (parents_log >= 8) {               // >= 256 parents: 256-lane workgroups, up to 5 levels each
+            u32 levels = remaining < 5 ? remaining : 5;
+            hipLaunchKernelGGL(k_merkle_up<256>, dim3(1u << (parents_log - 8)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
+            log_child -= levels;
+        } else {                              // the top of the tree (< 256 parents): one workgroup finishes it
+            hipLaunchKernelGGL(k_merkle_up<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
+            log_child -= remaining;
+        }
+    }
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
 }
 
 int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size_t n_cols, uint8_t *out) {
@@ -107,7 +212,9 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
     const size_t n_nodes = (size_t)1 << log_size;
     const u32 child_words = prev ? 16u : 0u;
     const u32 W = child_words + (u32)n_cols;
-    const unsigned blocks = ceil_div(n_nodes, 256);
+    unsigned blocks = ceil_div(n_nodes, 256);
+    const unsigned cap = (unsigned)c.n_cus * 8 * 4;        // 8 workgroups per CU x 4 nodes per lane before grid-striding more
+    if (blocks > cap) blocks = cap;
     // columns are absorbed kMaxHashCols per launch; launch boundaries fall on 64-byte block boundaries
     size_t col_base = 0;
     bool first = true;
@@ -167,14 +274,30 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
     const u32 **lc = n_cols ? new const u32 *[n_cols] : nullptr;
     const uint8_t *prev = nullptr;
     int rc = TSTWO_OK;
-    for (int lg = (int)max_log; lg >= 0 && rc == TSTWO_OK; lg--) {   // vcs/prover.ts:24-27
+    int lg = (int)max_log;
+    while (lg >= 0 && rc == TSTWO_OK) {   // vcs/prover.ts:24-27
         size_t k = 0;
         for (size_t i = 0; i < n_cols; i++)
             if (log_sizes[i] == (u32)lg) lc[k++] = cols[i];
         uint8_t *dst = layers + 32 * (((size_t)1 << lg) - 1);
         // layer k starts at 32*(2^k-1): 16-byte aligned for every k >= 0 when `layers` is
+        if (k == 0 && prev != nullptr && lg < 15) {
+            // a run of column-free layers below lg+1: fuse them (stop above the next layer that has columns)
+            int stop = lg;
+            while (stop > 0) {
+                bool has = false;
+                for (size_t i = 0; i < n_cols; i++) has = has || log_sizes[i] == (u32)(stop - 1);
+                if (has) break;
+                stop--;
+            }
+            rc = commit_upper_levels(layers, (u32)lg + 1, (u32)stop);
+            prev = layers + 32 * (((size_t)1 << stop) - 1);
+            lg = stop - 1;
+            continue;
+        }
         rc = commit_layer((u32)lg, prev, lc, k, dst);
         prev = dst;
+        lg--;
     }
     delete[] lc;
     if (rc) return rc;
