@@ -104,15 +104,32 @@ def main():
     # dlopen'ed so that both bind the same HIP runtime (same soname) in this process.
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    # "nccl" (= RCCL over xGMI) is the product path; TSTWO_DIST_BACKEND=gloo lets the N > 1 code path be rehearsed on a
+    # one-GPU box (all ranks share GPU 0, roots travel through host memory).
+    backend_name = os.environ.get("TSTWO_DIST_BACKEND", "nccl")
+    use_dist = world > 1 or bool(os.environ.get("TSTWO_FORCE_DIST"))   # FORCE: rehearse the collective path at world size 1
+    if use_dist:
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend_name, rank=rank, world_size=world)
+    root_dev = "cuda" if backend_name == "nccl" else "cpu"
 
     from tstwo_amd import _lib as L
     from tstwo_amd.backend import HipBackend, shard_columns
 
-    L.init(local_rank)
+    L.init(dev_index)
+    if use_dist and backend_name == "nccl":
+        # share torch's current stream: copy-root -> all-gather -> next step are then stream-ordered, no host sync per step
+        L.call("tstwo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
     backend = HipBackend()
 
     # ---- the rank's shard of the (world * n_cols) trace columns, resident in HBM
@@ -128,8 +145,8 @@ def main():
     L.call("tstwo_twiddles_build", half_initial, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
     layers = L.DeviceBuffer(32 * ((2 << n) - 1))
     log_sizes = L.u32x([n] * n_cols)
-    roots_local = torch.zeros(32, dtype=torch.uint8, device="cuda")
-    roots_all = torch.zeros(32 * world, dtype=torch.uint8, device="cuda")
+    roots_local = torch.zeros(32, dtype=torch.uint8, device=root_dev)
+    roots_all = torch.zeros(32 * world, dtype=torch.uint8, device=root_dev)
     L.sync()
 
     # HIP events on the library's stream, three per timed step, read after the timed region
@@ -144,15 +161,17 @@ def main():
         L.call("tstwo_merkle_commit", col_ptrs, log_sizes, n_cols, C.c_void_p(layers.ptr), None)
         if ev:
             ev[2].record()
-        if world > 1:   # the only exchange on the path: 32-byte roots over RCCL/xGMI
-            L.call("tstwo_copy", C.c_void_p(roots_local.data_ptr()), C.c_void_p(layers.ptr), 32)
-            L.sync()
+        if use_dist:   # the only exchange on the path: 32-byte roots over RCCL/xGMI
+            if root_dev == "cuda":
+                L.call("tstwo_copy", C.c_void_p(roots_local.data_ptr()), C.c_void_p(layers.ptr), 32)
+            else:
+                L.call("tstwo_download", C.c_void_p(roots_local.data_ptr()), C.c_void_p(layers.ptr), 32)
             dist.all_gather_into_tensor(roots_all, roots_local)
 
     def barrier():
         L.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         L.sync()
         torch.cuda.synchronize()
@@ -168,8 +187,8 @@ def main():
     t_cfft = sum(e[0].elapsed_ms(e[1]) for e in evs)
     t_merkle = sum(e[1].elapsed_ms(e[2]) for e in evs)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=root_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # roots of all ranks must have arrived and rank r's slot must hold rank r's root
@@ -181,7 +200,7 @@ def main():
         total_elems = world * n_cols * N * steps
         cfft_ms = t_cfft / steps
         merkle_ms = t_merkle / steps
-        # dominant kernel: k_cfft_pass<false>, launched (passes) times per step over all columns.
+        # dominant kernel: the CFFT pass kernels (k_cfft_a<K>, k_cfft_b13), (passes) launches per step over all columns.
         passes = 1 if n <= 13 else 1 + -(-(n - 13) // 9)
         algo_bytes_transform = 8.0 * N * n_cols                     # 8*N per column transform
         algo_bytes_launch = algo_bytes_transform / passes
@@ -218,7 +237,7 @@ def main():
             "merkle_ms": merkle_ms,
             "merkle_GBps": merkle_bytes / (merkle_ms * 1e-3) / 1e9,
             "merkle_frac_of_hbm_peak": merkle_bytes / (merkle_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": "k_cfft_pass<false>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9> + fast::k_cfft_b13<false> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "launches_per_step": passes, "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_launch},
@@ -230,7 +249,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
