@@ -100,7 +100,10 @@ point = T.SECURE_FIELD_CIRCLE_GEN
 vals = [T.QM31.from_u32_unchecked(7 + c, 8, 9, 10) for c in range(4)]
 batches = [T.ColumnSampleBatch(point, [(c, vals[c]) for c in range(4)])]
 coeff = T.QM31.from_u32_unchecked(1, 2, 3, 4)
-ms = timed(lambda: T.accumulateQuotients(dom, cols, coeff, batches, 1), reps=5)
+from tstwo_amd.quotients import marshal_quotient_args  # noqa: E402
+_keep, qargs = marshal_quotient_args(dom, cols, coeff, batches)
+qout = T.SecureColumnByCoords.uninitialized(N)
+ms = timed(lambda: L.call("tstwo_quotients_accumulate", *qargs, qout.ptrs()), reps=5)
 cpu = None
 if not args.no_cpu:
     s = 18
@@ -108,7 +111,7 @@ if not args.no_cpu:
     cpu = cpu_time(lambda: orc.accumulate_quotients(T.CanonicCoset(s).circleDomain().halfCoset.initial_index.value, s, sub, coeff.tup(),
                                                     [(point.x.tup(), point.y.tup(), [(c, vals[c].tup()) for c in range(4)])]),
                    1 << s, "rows", "2^18 rows (same per-row work)")
-emit(3, "accumulate_quotients C=4 log 22 (incl. host constants + output alloc)", ms, 32.0 * N, N, "rows", cpu)
+emit(3, "accumulate_quotients C=4 log 22 (C-ABI call: constant upload + kernel + error-flag readback)", ms, 32.0 * N, N, "rows", cpu)
 sec_h = [splitmix_column(8 + c, N) for c in range(4)]
 for c in sec_h:
     c[c == 0] = 1

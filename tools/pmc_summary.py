@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic, applying the gfx950
+corrections of MI355X_MICROARCH.md §HBM after calibrating them on kernels with known byte counts."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def load(root, counter):
+    out = defaultdict(list)
+    for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                out[(name, r["Grid_Size"])].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    ncal = (1 << 26) * 4.0
+    res = {"unit": "bytes per launch", "kernels": {}}
+    cal = {}
+    for (name, grid), v in fetch.items():
+        f = sum(v) / len(v) * 1024.0
+        w = sum(write.get((name, grid), [0])) / max(len(write.get((name, grid), [1])), 1) * 1024.0
+        if "binop_vec4" in name:
+            cal["fetch_16B"] = 2 * ncal / f if f else None
+            cal["write_16B"] = ncal / w if w else None
+        if "binop_scalar" in name:
+            cal["fetch_4B"] = 2 * ncal / f if f else None
+            cal["write_4B"] = ncal / w if w else None
+        res["kernels"][f"{name} grid={grid}"] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes_raw": w, "launches": len(v)}
+    res["calibration_true_over_counter"] = cal
+    k16 = cal.get("fetch_16B") or 2.0
+    for k, d in res["kernels"].items():
+        d["hbm_bytes_corrected"] = d["FETCH_SIZE_bytes_raw"] * k16 + d["WRITE_SIZE_bytes_raw"] * (cal.get("write_16B") or 1.0)
+    cf = [d for k, d in res["kernels"].items() if "k_cfft" in k]
+    if cf:
+        res["hbm_bytes_per_launch"] = sum(d["hbm_bytes_corrected"] for d in cf) / len(cf)   # avg over the transform's passes
+        res["algorithmic_bytes_per_launch"] = 8.0 * (1 << 22) * 32 / len(cf)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 --pmc passes: two calibration kernels with known byte counts (16-byte and 4-byte lane
+accesses), then the bench step (32 x 2^22 evaluate + Merkle commit) twice."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tstwo_amd import _lib as L  # noqa: E402
+
+L.init(0)
+vp = lambda p: C.c_void_p(p)
+ncal = 1 << 26
+a, b, o = L.DeviceBuffer(4 * ncal + 16), L.DeviceBuffer(4 * ncal + 16), L.DeviceBuffer(4 * ncal + 16)
+a.zero(); b.zero(); o.zero()
+L.call("tstwo_m31_add", vp(a.ptr), vp(b.ptr), vp(o.ptr), ncal)                    # k_m31_binop_vec4: 16 B per lane
+L.call("tstwo_m31_add", vp(a.ptr + 4), vp(b.ptr + 4), vp(o.ptr + 4), ncal)        # k_m31_binop_scalar: 4 B per lane
+n, cols = 22, 32
+N = 1 << n
+rng = np.random.default_rng(0)
+bufs = []
+for c in range(cols):
+    x = L.DeviceBuffer(4 * N)
+    x.upload(rng.integers(0, L.P, size=N, dtype=np.uint32))
+    bufs.append(x)
+ptrs = L.ptr_array([x.ptr for x in bufs])
+half = 1 << (31 - (n + 1))
+tw = L.DeviceBuffer(2 * N)
+L.call("tstwo_twiddles_build", half, n - 1, vp(tw.ptr), vp(0))
+layers = L.DeviceBuffer(32 * ((2 << n) - 1))
+for _ in range(2):
+    L.call("tstwo_cfft_evaluate", ptrs, cols, n, half, vp(tw.ptr), n - 1)
+    L.call("tstwo_merkle_commit", ptrs, L.u32x([n] * cols), cols, vp(layers.ptr), None)
+L.sync()
+print("done")

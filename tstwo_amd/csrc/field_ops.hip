@@ -195,6 +195,49 @@ __global__ void __launch_bounds__(256) k_bit_reverse(ColPtrs cols, u32 log_n) {
     }
 }
 
+// Tiled variant for log_n >= 12: index i = (a | m | b) with 6-bit a (top) and b (bottom) maps to
+// (rev b | rev m | rev a), so the 64x64-word tile with middle bits m trades places (transposed and bit-reversed
+// within) with tile rev(m).  Both tiles are staged in LDS; every global access is a 16-byte lane access on
+// 256-byte runs, instead of the scattered 4-byte swaps of k_bit_reverse.
+__global__ void __launch_bounds__(256) k_bit_reverse_tiled(ColPtrs cols, u32 log_n) {
+    constexpr int T = 6, S = 1 << T, STRIDE = S + 1;
+    __shared__ u32 lds[2][S * STRIDE];
+    u32 *__restrict__ v = cols.p[blockIdx.y];
+    const u32 mid_bits = log_n - 2 * T;
+    const u32 m = blockIdx.x;
+    const u32 rm = mid_bits ? (__brev(m) >> (32 - mid_bits)) : 0u;
+    if (rm < m) return;                                  // the pair is handled by the block of the smaller index
+    const u32 row_shift = log_n - T;
+    for (int which = 0; which < (rm == m ? 1 : 2); which++) {
+        const u32 mm = which ? rm : m;
+#pragma unroll
+        for (int it = 0; it < S * S / (256 * 4); it++) {
+            const u32 idx4 = threadIdx.x + it * 256;
+            const u32 a = idx4 / (S / 4), b4 = (idx4 % (S / 4)) * 4;
+            const uint4 x = *reinterpret_cast<const uint4 *>(v + (((size_t)a << row_shift) | ((size_t)mm << T) | b4));
+            u32 *p = &lds[which][a * STRIDE + b4];
+            p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
+        }
+    }
+    __syncthreads();
+    for (int which = 0; which < (rm == m ? 1 : 2); which++) {
+        const u32 dst = which ? m : rm;                  // tile m's words land in tile rev(m) and vice versa
+        const u32 *L = lds[which];
+#pragma unroll
+        for (int it = 0; it < S * S / (256 * 4); it++) {
+            const u32 idx4 = threadIdx.x + it * 256;
+            const u32 r = idx4 / (S / 4), c4 = (idx4 % (S / 4)) * 4;
+            const u32 rr = __brev(r) >> (32 - T);
+            uint4 x;
+            x.x = L[(__brev(c4 + 0) >> (32 - T)) * STRIDE + rr];
+            x.y = L[(__brev(c4 + 1) >> (32 - T)) * STRIDE + rr];
+            x.z = L[(__brev(c4 + 2) >> (32 - T)) * STRIDE + rr];
+            x.w = L[(__brev(c4 + 3) >> (32 - T)) * STRIDE + rr];
+            *reinterpret_cast<uint4 *>(v + (((size_t)r << row_shift) | ((size_t)dst << T) | c4)) = x;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- twiddle tree (backend/cpu/circle.ts:210-221)
 // Entry e of the tree of coset (init, m): level lvl holds the x coordinates of the first half of
 // coset.repeated_double(lvl), bit-reversed; the last entry is 1.
@@ -238,9 +281,16 @@ int tstwo_m31_neg(const u32 *a, u32 *out, size_t n) { return launch_binop<OP_NEG
 int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
-    constexpr int K = 16;
-    size_t T = (n + K - 1) / K;
-    hipLaunchKernelGGL(k_m31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, in, out, n, T, ctx().flag);
+    // elements per lane: enough lanes to fill the chip first, then amortise the 37-multiplication Fermat chain
+    if (n >= ((size_t)1 << 24)) {
+        constexpr int K = 16;
+        size_t T = (n + K - 1) / K;
+        hipLaunchKernelGGL(k_m31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, in, out, n, T, ctx().flag);
+    } else {
+        constexpr int K = 4;
+        size_t T = (n + K - 1) / K;
+        hipLaunchKernelGGL(k_m31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, in, out, n, T, ctx().flag);
+    }
     TSTWO_LAUNCH_CHECK();
     return finish_inverse();
 }
@@ -297,8 +347,14 @@ int tstwo_bit_reverse(u32 *const *cols, size_t n_cols, size_t n) {
         size_t cnt = n_cols - base < (size_t)kMaxColsPerLaunch ? n_cols - base : (size_t)kMaxColsPerLaunch;
         ColPtrs cp;
         for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[base + i];
-        unsigned blocks = capped_blocks(n, 256);
-        hipLaunchKernelGGL(k_bit_reverse, dim3(blocks, (unsigned)cnt), dim3(256), 0, ctx().stream, cp, log_n);
+        bool aligned = true;
+        for (size_t i = 0; i < cnt; i++) aligned = aligned && ((((uintptr_t)cp.p[i]) & 15) == 0);
+        if (log_n >= 12 && log_n <= 40 && aligned) {
+            hipLaunchKernelGGL(k_bit_reverse_tiled, dim3(1u << (log_n - 12), (unsigned)cnt), dim3(256), 0, ctx().stream, cp, log_n);
+        } else {
+            unsigned blocks = capped_blocks(n, 256);
+            hipLaunchKernelGGL(k_bit_reverse, dim3(blocks, (unsigned)cnt), dim3(256), 0, ctx().stream, cp, log_n);
+        }
     }
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;

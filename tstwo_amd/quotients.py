@@ -42,11 +42,9 @@ def quotientConstants(sample_batches, random_coeff: QM31, ts_compat: bool = Fals
     return line_coeffs, batch_coeffs
 
 
-def accumulateQuotients(domain: CircleDomain, columns, random_coeff: QM31, sample_batches, _log_blowup_factor: int = 1,
-                        ts_compat: bool = False) -> SecureEvaluation:
-    """accumulateQuotients (quotients.ts:52-75).  Default = Rust semantics (QM31 conjugation (c0,-c1); Pr/Pi = the
-    c0/c1 parts of the sample point).  ts_compat=True reproduces the TS port's deviations (per-CM31 conjugation,
-    qm31.ts:433-435; Pr/Pi taken from c0.real/c0.imag, quotients.ts:168-174) — see DESIGN.md "reference quirks"."""
+def marshal_quotient_args(domain: CircleDomain, columns, random_coeff: QM31, sample_batches, ts_compat: bool = False):
+    """Host-side part of accumulateQuotients: quotientConstants() + flattening into the C ABI's arrays.
+    Returns (vals, args) where args is the argument tuple of tstwo_quotients_accumulate minus the output."""
     line_coeffs, batch_coeffs = quotientConstants(sample_batches, random_coeff, ts_compat)
     off, cidx, abc, bco, prx, pry, pix, piy = [0], [], [], [], [], [], [], []
     zero = M31.zero()
@@ -67,10 +65,19 @@ def accumulateQuotients(domain: CircleDomain, columns, random_coeff: QM31, sampl
     for v in vals:
         if v.len() != domain.size():
             raise ValueError("column length does not match the domain size")
+    args = (domain.halfCoset.initial_index.value, domain.log_size(), L.ptr_array([v.ptr for v in vals]), len(vals),
+            len(sample_batches), L.u32x(off), L.u32x(cidx), L.u32x(abc), L.u32x(bco), L.u32x(prx), L.u32x(pry), L.u32x(pix), L.u32x(piy))
+    return vals, args
+
+
+def accumulateQuotients(domain: CircleDomain, columns, random_coeff: QM31, sample_batches, _log_blowup_factor: int = 1,
+                        ts_compat: bool = False) -> SecureEvaluation:
+    """accumulateQuotients (quotients.ts:52-75).  Default = Rust semantics (QM31 conjugation (c0,-c1); Pr/Pi = the
+    c0/c1 parts of the sample point).  ts_compat=True reproduces the TS port's deviations (per-CM31 conjugation,
+    qm31.ts:433-435; Pr/Pi taken from c0.real/c0.imag, quotients.ts:168-174) — see DESIGN.md "reference quirks"."""
+    _vals, args = marshal_quotient_args(domain, columns, random_coeff, sample_batches, ts_compat)
     out = SecureColumnByCoords.uninitialized(domain.size())
-    L.call("tstwo_quotients_accumulate", domain.halfCoset.initial_index.value, domain.log_size(),
-           L.ptr_array([v.ptr for v in vals]), len(vals), len(sample_batches), L.u32x(off), L.u32x(cidx), L.u32x(abc),
-           L.u32x(bco), L.u32x(prx), L.u32x(pry), L.u32x(pix), L.u32x(piy), out.ptrs())
+    L.call("tstwo_quotients_accumulate", *args, out.ptrs())
     return SecureEvaluation(domain, out)
 
 
