@@ -140,6 +140,10 @@ int tstwo_merkle_commit_layer(uint32_t log_size, const uint8_t *prev, const uint
 int tstwo_merkle_commit(const uint32_t *const *cols, const uint32_t *log_sizes, size_t n_cols,
                         uint8_t *layers, uint8_t root[32]);
 size_t tstwo_merkle_layers_bytes(uint32_t max_log);
+/* Gather for MerkleProver.decommit (vcs/prover.ts:32-109): item i = `words` consecutive uint32 words starting at
+ * word index idx[i]*words of the device buffer srcs[i] (a column: words = 1; a layer of digests: words = 8).
+ * Results land contiguously in host_out (n_items * words words).  srcs / idx are host arrays.  Synchronises. */
+int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, uint32_t words, size_t n_items, uint32_t *host_out);
 
 /* ---------------------------------------------------------------- QuotientOps
  * accumulateQuotients row loop (backend/cpu/quotients.ts:52-116,160-178) with the per-batch constants

@@ -299,3 +299,75 @@ def test_accumulate(backend):
         assert (x == y).all()
     with pytest.raises(ValueError, match="column length mismatch"):
         T.accumulate(a, T.SecureColumnByCoords.zeros(3))
+
+
+# ---------------------------------------------------------------- vcs/blake2_merkle.test.ts, vcs/prover.test.ts (decommit / verify)
+def _prepare_merkle(golden):
+    """prepareMerkle (vcs/test_utils.ts:47-144): LCG seed 0, 10 columns of log 3..4, 3 queries per log size."""
+    e = golden["merkle_lcg"]
+    s = [0]
+
+    def nxt():
+        s[0] = (1664525 * s[0] + 1013904223) % 2**32
+        return s[0]
+
+    log_sizes = [3 + nxt() % 2 for _ in range(10)]
+    cols_np = [[nxt() % (1 << 30) for _ in range(1 << lg)] for lg in log_sizes]
+    assert log_sizes == e["log_sizes"] and cols_np == e["cols"]
+    queries = {}
+    for lg in (4, 3):
+        queries[lg] = sorted(set(nxt() % (1 << lg) for _ in range(3)))
+    cols = [T.HipColumn(np.array(c, dtype=np.uint32)) for c in cols_np]
+    tree = T.MerkleProver.commit(cols)
+    values, dec = tree.decommit(queries, cols)
+    verifier = T.MerkleVerifier(T.Blake2sMerkleHasher(), tree.root(), log_sizes)
+    return queries, dec, values, verifier, cols_np, log_sizes
+
+
+def test_merkle_decommit_verify_roundtrip(golden):
+    queries, dec, values, verifier, cols_np, log_sizes = _prepare_merkle(golden)
+    verifier.verify(queries, values, dec)                                  # test_merkle_success
+    # queried values are exactly the queried rows of the columns of that size, largest layer first
+    exp = []
+    order = sorted(range(10), key=lambda i: -log_sizes[i])
+    for lg in (4, 3):
+        for q in queries[lg]:
+            exp += [cols_np[i][q] for i in order if log_sizes[i] == lg]
+    assert [v.value for v in values] == exp
+
+
+def test_merkle_verify_failures(golden):
+    """vcs/blake2_merkle.test.ts:30-100: the verifier's error cases."""
+    import copy
+    queries, dec, values, verifier, *_ = _prepare_merkle(golden)
+    d = copy.deepcopy(dec); d.hashWitness[4] = bytes(32)
+    with pytest.raises(ValueError, match="Root mismatch."):
+        verifier.verify(queries, values, d)
+    v = list(values); v[6] = T.M31(0)
+    with pytest.raises(ValueError, match="Root mismatch."):
+        verifier.verify(queries, v, dec)
+    d = copy.deepcopy(dec); d.hashWitness.pop()
+    with pytest.raises(ValueError, match="Witness is too short"):
+        verifier.verify(queries, values, d)
+    d = copy.deepcopy(dec); d.hashWitness.append(bytes(32))
+    with pytest.raises(ValueError, match="Witness is too long."):
+        verifier.verify(queries, values, d)
+    d = copy.deepcopy(dec); d.columnWitness.append(T.M31(0))
+    with pytest.raises(ValueError, match="Witness is too long."):
+        verifier.verify(queries, values, d)
+    with pytest.raises(ValueError, match="too many Queried values"):
+        verifier.verify(queries, list(values) + [T.M31(0)], dec)
+    with pytest.raises(ValueError, match="too few queried values"):
+        verifier.verify(queries, list(values)[:-1], dec)
+
+
+def test_merkle_decommit_large():
+    """log 16, 6 columns of two sizes, 40 random queries: decommit from device layers verifies against the root."""
+    rng = np.random.default_rng(7)
+    log_sizes = [16, 16, 16, 14, 14, 16]
+    cols = [T.HipColumn(rand_column(300 + i, 1 << lg)) for i, lg in enumerate(log_sizes)]
+    tree = T.MerkleProver.commit(cols)
+    queries = {16: sorted(set(int(x) for x in rng.integers(0, 1 << 16, 40))), 14: sorted(set(int(x) for x in rng.integers(0, 1 << 14, 40)))}
+    values, dec = tree.decommit(queries, cols)
+    T.MerkleVerifier(T.Blake2sMerkleHasher(), tree.root(), log_sizes).verify(queries, values, dec)
+    assert len(dec.hashWitness) > 0 and all(len(h) == 32 for h in dec.hashWitness)

@@ -14,6 +14,7 @@ from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureEva
                    evaluate_polynomials, interpolate_columns, precompute_twiddles)
 from .quotients import (ColumnSampleBatch, accumulate, accumulateQuotients, generate_secure_powers,  # noqa: F401
                         quotientConstants)
-from .vcs import DeviceHashLayer, HipMerkleOps, MerkleProver  # noqa: F401
+from .vcs import (Blake2sMerkleHasher, DeviceHashLayer, HipMerkleOps, MerkleDecommitment, MerkleProver,  # noqa: F401
+                  MerkleVerifier)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

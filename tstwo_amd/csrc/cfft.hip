@@ -349,7 +349,8 @@ int launch_pass(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
 
 u32 pick_cols_per_wg(size_t tiles, size_t cnt) {
     // columns per workgroup: amortise the twiddle staging, but keep >= ~8 workgroups per CU in the grid
-    u32 cpw = 4;
+    u32 cpw = 8;   // measured 32 x 2^22: 747 / 703 / 678 / 671 / 672 us for 1 / 2 / 4 / 8 / 16 columns per workgroup
+    { const char *e = getenv("TSTWO_CFFT_CPW"); if (e && atoi(e) > 0) cpw = (u32)atoi(e); }
     while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)ctx().n_cus * 8) cpw >>= 1;
     if (cpw > cnt) cpw = (u32)cnt;
     return cpw;
@@ -444,21 +445,33 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     const bool fast_path = n >= kMaxLogTileB && n <= 28;
     const char *dbg_env = getenv("TSTWO_CFFT_GENERIC");      // debugging aid: 1 = generic kernel for the bottom pass, 2 = for strided passes
     const int dbg_generic = dbg_env ? atoi(dbg_env) : 0;      // specialised kernels (cfft_fast.cuh); smaller sizes use the generic one
-    if (!INV) {
-        for (int s = np - 1; s >= 0; s--) {
-            if ((dbg_generic & 4) && passes[s].lo == 0) continue;
-            const bool f = fast_path && !(dbg_generic & (passes[s].lo == 0 ? 1 : 2));
-            int rc = f ? launch_fast<false>(cols, n_cols, n, passes[s], tw_end, 0)
-                               : launch_pass<false>(cols, n_cols, n, passes[s], tw, tw_log, 0);
-            if (rc) return rc;
-        }
-    } else {
-        for (int s = 0; s < np; s++) {
-            const u32 sc = s == np - 1 ? n_inv : 0;
-            const bool f = fast_path && !(dbg_generic & (passes[s].lo == 0 ? 1 : 2));
-            int rc = f ? launch_fast<true>(cols, n_cols, n, passes[s], tw_end, sc)
-                               : launch_pass<true>(cols, n_cols, n, passes[s], tw, tw_log, sc);
-            if (rc) return rc;
+    // All columns go through a pass in one launch.  (Measured on MI355X, 32 x 2^22: running the passes back to back
+    // on Infinity-Cache-sized column groups is slower — 688 us ungrouped vs 724/771/879 us for groups of 16/8/4 —
+    // the extra launch tails cost more than MALL residency of the intermediate returns.  TSTWO_CFFT_GROUP=k re-enables it.)
+    size_t group = n_cols;
+    {
+        const char *ge = getenv("TSTWO_CFFT_GROUP");
+        if (np > 1 && ge && atoi(ge) > 0 && (size_t)atoi(ge) < n_cols) group = (size_t)atoi(ge);
+    }
+    for (size_t g0 = 0; g0 < n_cols; g0 += group) {
+        const size_t gc = n_cols - g0 < group ? n_cols - g0 : group;
+        u32 *const *gcols = cols + g0;
+        if (!INV) {
+            for (int s = np - 1; s >= 0; s--) {
+                if ((dbg_generic & 4) && passes[s].lo == 0) continue;
+                const bool f = fast_path && !(dbg_generic & (passes[s].lo == 0 ? 1 : 2));
+                int rc = f ? launch_fast<false>(gcols, gc, n, passes[s], tw_end, 0)
+                           : launch_pass<false>(gcols, gc, n, passes[s], tw, tw_log, 0);
+                if (rc) return rc;
+            }
+        } else {
+            for (int s = 0; s < np; s++) {
+                const u32 sc = s == np - 1 ? n_inv : 0;
+                const bool f = fast_path && !(dbg_generic & (passes[s].lo == 0 ? 1 : 2));
+                int rc = f ? launch_fast<true>(gcols, gc, n, passes[s], tw_end, sc)
+                           : launch_pass<true>(gcols, gc, n, passes[s], tw, tw_log, sc);
+                if (rc) return rc;
+            }
         }
     }
     return TSTWO_OK;

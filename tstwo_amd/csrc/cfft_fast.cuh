@@ -97,7 +97,7 @@ __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
 // ------------------------------------------------------------------------------------------------
 // Bottom pass: layers 0..12 (circle layer included) of a contiguous 2^13-word tile.
 template <bool INV>
-__global__ void __launch_bounds__(512) k_cfft_b13(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
+__global__ void __launch_bounds__(512, 8) k_cfft_b13(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
                                                  const u32 *__restrict__ tw_end, u32 scale) {
     constexpr int LOGT = 13, THREADS = 512;
     constexpr u32 T = 1u << LOGT, QT = T / 4;
@@ -266,8 +266,8 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
         }
     }
     // element offsets of this lane's 16 words in the final-stage layout (R > 0)
-    auto e_final = [&](int g, int m) -> u32 {
-        const u32 gid = t + (u32)g * THREADS;
+    auto e_final = [&](u32 tt, int g, int m) -> u32 {
+        const u32 gid = tt + (u32)g * THREADS;
         const u32 low = gid & ((1u << C) - 1u), high = gid >> C;
         return (high << (C + G2)) | ((u32)m << C) | low;
     };
@@ -283,6 +283,8 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
         for (u32 col = col0; col < col1; col++) {
             u32 *__restrict__ data = cols.p[col] + base;
             const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+            u32 tt = t;
+            asm volatile("" : "+v"(tt));     // opaque per iteration: keeps the 16 scatter addresses out of loop-invariant registers
             top_layers<INV, F == 2>(pf, ta, tb0, tb1);
             if constexpr (R == 0) {
 #pragma unroll
@@ -312,10 +314,10 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
                     const u32 high = (t + (u32)g * THREADS) >> C;
                     u32 v[1 << G2];
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) v[m] = lds[pad(e_final(g, 0)) + off<C>(m)];
+                    for (int m = 0; m < (1 << G2); m++) v[m] = lds[pad(e_final(tt, g, 0)) + off<C>(m)];
                     group_layers<G2, C, LOGT, false>(v, twl, high);
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) data[goff(e_final(g, m))] = v[m];
+                    for (int m = 0; m < (1 << G2); m++) data[goff(e_final(tt, g, m))] = v[m];
                 }
                 lds_barrier();
             }
@@ -324,15 +326,18 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
         // inverse with LDS stages: the lane's 16 words arrive in the first-stage layout
         u32 pfs[16];
         {
+            const u32 tt = t;
             const u32 *__restrict__ d = cols.p[col0] + base;
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = d[goff(e_final(g, m))];
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = d[goff(e_final(tt, g, m))];
         }
         for (u32 col = col0; col < col1; col++) {
             u32 *__restrict__ data = cols.p[col] + base;
             const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+            u32 tt = t;
+            asm volatile("" : "+v"(tt));
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++) {
                 const u32 high = (t + (u32)g * THREADS) >> C;
@@ -341,13 +346,13 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
                 for (int m = 0; m < (1 << G2); m++) v[m] = pfs[g * (1 << G2) + m];
                 group_layers<G2, C, LOGT, true>(v, twl, high);
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(g, 0)) + off<C>(m)] = v[m];
+                for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(tt, g, 0)) + off<C>(m)] = v[m];
             }
             lds_barrier();
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = next[goff(e_final(g, m))];
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = next[goff(e_final(tt, g, m))];
             if constexpr (G1 > 0) {
                 lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl);
                 lds_barrier();

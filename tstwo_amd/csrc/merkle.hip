@@ -204,6 +204,14 @@ int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
     return TSTWO_OK;
 }
 
+struct GatherItem { const u32 *src; unsigned long long idx; };
+__global__ void __launch_bounds__(256) k_gather_words(const GatherItem *__restrict__ items, u32 words, size_t total, u32 *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t item = i / words, w = i % words;
+    out[i] = items[item].src[items[item].idx * words + w];
+}
+
 int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size_t n_cols, uint8_t *out) {
     Context &c = ctx();
     if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");
@@ -256,6 +264,29 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
 extern "C" {
 
 size_t tstwo_merkle_layers_bytes(u32 max_log) { return 32u * (((size_t)2 << max_log) - 1); }
+
+int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, u32 words, size_t n_items, u32 *host_out) {
+    TSTWO_REQUIRE_READY();
+    if (n_items == 0 || words == 0) return TSTWO_OK;
+    if (!srcs || !idx || !host_out) return set_error(TSTWO_ERR_BAD_ARG, "gather: null argument");
+    Context &c = ctx();
+    const size_t total = n_items * words;
+    const size_t items_bytes = ((n_items * sizeof(GatherItem) + 63) / 64) * 64;
+    int rc = ensure_scratch(items_bytes + total * sizeof(u32));
+    if (rc) return rc;
+    GatherItem *h = new GatherItem[n_items];
+    for (size_t i = 0; i < n_items; i++) { h[i].src = (const u32 *)srcs[i]; h[i].idx = idx[i]; }
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    hipError_t e = hipMemcpy(c.scratch, h, n_items * sizeof(GatherItem), hipMemcpyHostToDevice);
+    delete[] h;
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(gather items)");
+    u32 *d_out = (u32 *)((unsigned char *)c.scratch + items_bytes);
+    hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(total, 256)), dim3(256), 0, c.stream, (const GatherItem *)c.scratch, words, total, d_out);
+    TSTWO_LAUNCH_CHECK();
+    TSTWO_HIP(hipMemcpyAsync(host_out, d_out, total * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    return TSTWO_OK;
+}
 
 int tstwo_merkle_commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size_t n_cols, uint8_t *out) {
     TSTWO_REQUIRE_READY();

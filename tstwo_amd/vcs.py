@@ -6,8 +6,12 @@ import ctypes as C
 
 import numpy as np
 
+import hashlib
+from dataclasses import dataclass, field
+
 from . import _lib as L
 from .backend import HipColumn, _vp
+from .fields import M31
 
 
 class DeviceHashLayer:
@@ -68,3 +72,178 @@ class MerkleProver:
 
     def root(self) -> bytes:
         return self._root
+
+    def decommit(self, queriesPerLogSize: dict, columns) -> tuple:
+        """MerkleProver.decommit (vcs/prover.ts:32-109): returns (queried_values, MerkleDecommitment).
+        The walk over the layers is the reference's; the digests / column words it selects are fetched from the
+        device-resident layers and columns with two gathers (tstwo_gather_words) instead of per-element reads."""
+        sorted_cols = sorted(columns, key=lambda c: -c.len())                 # stable, like the JS sort
+        col_i = 0
+        hash_req, queried_req, witness_req = [], [], []                       # (device ptr, index) requests, in order
+        last_nodes = []
+        n_layers = len(self.layers)
+        for log in range(n_layers - 1, -1, -1):
+            layer_cols = []
+            while col_i < len(sorted_cols) and sorted_cols[col_i].len() == (1 << log):
+                layer_cols.append(sorted_cols[col_i])
+                col_i += 1
+            child = self.layers[log + 1] if log + 1 < n_layers else None
+            cur_nodes = []
+            parents = _Peekable(last_nodes)
+            direct = _Peekable(queriesPerLogSize.get(log) or [])
+            while True:
+                node = next_decommitment_node(parents, direct)
+                if node is None:
+                    break
+                if child is not None:
+                    for k in (2 * node, 2 * node + 1):
+                        if parents.peek() == k:
+                            parents.next()
+                        else:
+                            hash_req.append((child.ptr, k))
+                reqs = [(c.ptr, node) for c in layer_cols]
+                if direct.peek() == node:
+                    direct.next()
+                    queried_req += reqs
+                else:
+                    witness_req += reqs
+                cur_nodes.append(node)
+            last_nodes = cur_nodes
+        hashes = _gather(hash_req, 8)
+        vals = _gather(queried_req + witness_req, 1)
+        nq = len(queried_req)
+        queried = [M31(int(v)) for v in vals[:nq]]
+        dec = MerkleDecommitment([hashes[8 * i:8 * i + 8].tobytes() for i in range(len(hash_req))],
+                                 [M31(int(v)) for v in vals[nq:]])
+        return queried, dec
+
+
+def _gather(reqs, words: int) -> np.ndarray:
+    out = np.empty(len(reqs) * words, dtype=np.uint32)
+    if reqs:
+        srcs = L.ptr_array([p for p, _ in reqs])
+        idx = (C.c_uint64 * len(reqs))(*[i for _, i in reqs])
+        L.call("tstwo_gather_words", srcs, idx, words, len(reqs), out.ctypes.data_as(L.u32p))
+    return out
+
+
+class _Peekable:
+    """vcs/utils.ts:8-32."""
+
+    def __init__(self, it):
+        self._it = iter(it)
+        self._buf = []
+
+    def peek(self):
+        if not self._buf:
+            try:
+                self._buf.append(next(self._it))
+            except StopIteration:
+                return None
+        return self._buf[0]
+
+    def next(self):
+        v = self.peek()
+        if self._buf:
+            self._buf.pop(0)
+        return v
+
+
+def next_decommitment_node(prev_queries: _Peekable, layer_queries: _Peekable):
+    """vcs/utils.ts:40-57."""
+    cands = []
+    p = prev_queries.peek()
+    if p is not None:
+        cands.append(p // 2)
+    q = layer_queries.peek()
+    if q is not None:
+        cands.append(q)
+    return min(cands) if cands else None
+
+
+@dataclass
+class MerkleDecommitment:
+    """vcs/verifier.ts:5-8."""
+    hashWitness: list = field(default_factory=list)      # 32-byte digests
+    columnWitness: list = field(default_factory=list)    # M31
+
+
+class Blake2sMerkleHasher:
+    """hashNode (vcs/blake2_merkle.ts:9-24) on the host — used by the verifier only (a handful of nodes)."""
+
+    @staticmethod
+    def hashNode(children, column_values) -> bytes:
+        h = hashlib.blake2s()
+        if children is not None:
+            h.update(children[0])
+            h.update(children[1])
+        for v in column_values:
+            h.update(int(v.value if isinstance(v, M31) else v).to_bytes(4, "little"))
+        return h.digest()
+
+
+class MerkleVerifier:
+    """MerkleVerifier (vcs/verifier.ts:15-147), same error texts."""
+
+    def __init__(self, hasher, root: bytes, column_log_sizes):
+        self.hasher, self.root, self.columnLogSizes = hasher, root, list(column_log_sizes)
+        self.nColumnsPerLogSize = {}
+        for lg in self.columnLogSizes:
+            self.nColumnsPerLogSize[lg] = self.nColumnsPerLogSize.get(lg, 0) + 1
+
+    def verify(self, queriesPerLogSize: dict, queriedValues, decommitment: MerkleDecommitment) -> None:
+        if not self.columnLogSizes:
+            return
+        max_log = max(self.columnLogSizes)
+        qi = hi = ci = 0
+        last = None
+        for log in range(max_log, -1, -1):
+            n_cols = self.nColumnsPerLogSize.get(log, 0)
+            total = []
+            prev_q = _Peekable([q for q, _ in (last or [])])
+            prev_h = _Peekable(last) if last is not None else None
+            layer_q = _Peekable(queriesPerLogSize.get(log) or [])
+            while True:
+                node = next_decommitment_node(prev_q, layer_q)
+                if node is None:
+                    break
+                while prev_q.peek() is not None and prev_q.peek() // 2 == node:
+                    prev_q.next()
+                node_hashes = None
+                if prev_h is not None:
+                    pair = []
+                    for k in (2 * node, 2 * node + 1):
+                        pk = prev_h.peek()
+                        if pk is not None and pk[0] == k:
+                            pair.append(prev_h.next()[1])
+                        else:
+                            if hi >= len(decommitment.hashWitness):
+                                raise ValueError("Witness is too short")
+                            pair.append(decommitment.hashWitness[hi])
+                            hi += 1
+                    node_hashes = tuple(pair)
+                from_queried = layer_q.peek() == node
+                if from_queried:
+                    layer_q.next()
+                vals = []
+                for _ in range(n_cols):
+                    if from_queried:
+                        if qi >= len(queriedValues):
+                            raise ValueError("too few queried values")
+                        vals.append(queriedValues[qi])
+                        qi += 1
+                    else:
+                        if ci >= len(decommitment.columnWitness):
+                            raise ValueError("Witness is too short")
+                        vals.append(decommitment.columnWitness[ci])
+                        ci += 1
+                total.append((node, self.hasher.hashNode(node_hashes, vals)))
+            last = total
+        if hi != len(decommitment.hashWitness):
+            raise ValueError("Witness is too long.")
+        if qi != len(queriedValues):
+            raise ValueError("too many Queried values")
+        if ci != len(decommitment.columnWitness):
+            raise ValueError("Witness is too long.")
+        if last[0][1] != self.root:
+            raise ValueError("Root mismatch.")
