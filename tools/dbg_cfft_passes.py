@@ -1,49 +1,59 @@
-import os, sys, ctypes as C
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Debug aid: compares the specialised CFFT pass kernels with the generic kernel and the CPU oracle.
+TSTWO_CFFT_GENERIC bit 0: generic bottom pass, bit 1: generic strided passes, bit 2: skip the bottom pass."""
+import ctypes as C
+import os
+import sys
+
 import numpy as np
-from tstwo_amd import _lib as L
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402
+from tstwo_amd import _lib as L  # noqa: E402
+
 L.init(0)
-n=int(sys.argv[1]) if len(sys.argv)>1 else 16
-N=1<<n
-rng=np.random.default_rng(0)
-a=rng.integers(0,L.P,size=N,dtype=np.uint32)
-half=1<<(31-(n+1))
-tw=L.DeviceBuffer(2*N)
-L.call("tstwo_twiddles_build", half, n-1, C.c_void_p(tw.ptr), C.c_void_p(0))
-def run(mode):
-    os.environ["TSTWO_CFFT_GENERIC"]=str(mode)
-    b=L.DeviceBuffer(4*N); b.upload(a)
-    L.call("tstwo_cfft_evaluate", L.ptr_array([b.ptr]), 1, n, half, C.c_void_p(tw.ptr), n-1)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+N = 1 << n
+rng = np.random.default_rng(0)
+a = rng.integers(0, L.P, size=N, dtype=np.uint32)
+half = 1 << (31 - (n + 1))
+tw, itw = L.DeviceBuffer(2 * N), L.DeviceBuffer(2 * N)
+L.call("tstwo_twiddles_build", half, n - 1, C.c_void_p(tw.ptr), C.c_void_p(itw.ptr))
+
+
+def run(mode, inverse=False, data=a):
+    os.environ["TSTWO_CFFT_GENERIC"] = str(mode)
+    b = L.DeviceBuffer(4 * N)
+    b.upload(data)
+    fn = "tstwo_cfft_interpolate" if inverse else "tstwo_cfft_evaluate"
+    L.call(fn, L.ptr_array([b.ptr]), 1, n, half, C.c_void_p((itw if inverse else tw).ptr), n - 1)
     L.sync()
     return b.download(np.uint32, N)
-good=run(4|2); bad=run(4)
-d=np.nonzero(good!=bad)[0]
-print("n",n,"pass A only: mismatches",d.size,"of",N)
-P=L.P
-otw=None
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import oracle as orc
-otw,_=orc.precompute_twiddles(half,n-1,inverse=False); Lw=len(otw)
-def layer(v,i):
-    v=v.astype(np.uint64).copy()
-    for h in range(1<<(n-1-i)):
-        t=int(otw[Lw-(1<<(n-i))+h])
-        x=np.arange(1<<i)+(h<<(i+1)); y=x+(1<<i)
-        m=v[y]*t%P; a0=v[x].copy()
-        v[x]=(a0+m)%P; v[y]=(a0+P-m)%P
-    return v
-v=a
-for i in range(n-1,12,-1):
-    v=layer(v,i)
-    print("after layer",i,": equals fast?", (v==bad).all(), " equals generic?", (v==good).all())
-print("input", a[:6]); print("good ", good[:6]); print("fast ", bad[:6])
-v2=layer(layer(a,15),14)
-# hypotheses for the last layer's twiddle
-for name,tfun in [("t=0",lambda t:0),("t=1",lambda t:1),("2t",lambda t:2*t%P),("t/2",lambda t:t*pow(2,P-2,P)%P)]:
-    v=v2.astype(np.uint64).copy(); i=13
-    for h in range(1<<(n-1-i)):
-        t=tfun(int(otw[Lw-(1<<(n-i))+h]))
-        x=np.arange(1<<i)+(h<<(i+1)); y=x+(1<<i)
-        m=v[y]*t%P; a0=v[x].copy(); v[x]=(a0+m)%P; v[y]=(a0+P-m)%P
-    print(name, (v==bad).all(), int((v==bad).sum()))
-print("fast==input?", (bad==a).sum(), " fast==after15,14?", (bad==v2).sum())
+
+
+otw, oitw = orc.precompute_twiddles(half, n - 1)
+full = orc.cfft_evaluate(a, n, half, otw, n - 1)
+for mode, name in [(3, "generic/generic"), (2, "fast bottom, generic strided"), (1, "generic bottom, fast strided"), (0, "fast/fast")]:
+    got = run(mode)
+    print(f"evaluate  {name:32s}: {'OK' if (got == full).all() else 'MISMATCH %d' % int((got != full).sum())}")
+    back = run(mode, inverse=True, data=full)
+    print(f"interpolate {name:30s}: {'OK' if (back == a).all() else 'MISMATCH %d' % int((back != a).sum())}")
+
+# multi-column (columns-per-workgroup loop): 5 columns, forced cpw values
+ncol = 5
+cols_h = [rng.integers(0, L.P, size=N, dtype=np.uint32) for _ in range(ncol)]
+exp = [orc.cfft_evaluate(c, n, half, otw, n - 1) for c in cols_h]
+for cpw in (1, 2, 4, 8):
+    os.environ["TSTWO_CFFT_CPW"] = str(cpw)
+    for mode, name in [(2, "fast bottom only"), (1, "fast strided only"), (0, "fast/fast")]:
+        os.environ["TSTWO_CFFT_GENERIC"] = str(mode)
+        bufs = []
+        for c in cols_h:
+            b = L.DeviceBuffer(4 * N); b.upload(c); bufs.append(b)
+        L.call("tstwo_cfft_evaluate", L.ptr_array([b.ptr for b in bufs]), ncol, n, half, C.c_void_p(tw.ptr), n - 1)
+        L.sync()
+        bad = [i for i, b in enumerate(bufs) if not (b.download(np.uint32, N) == exp[i]).all()]
+        L.call("tstwo_cfft_interpolate", L.ptr_array([b.ptr for b in bufs]), ncol, n, half, C.c_void_p(itw.ptr), n - 1)
+        L.sync()
+        badi = [i for i, b in enumerate(bufs) if not (b.download(np.uint32, N) == cols_h[i]).all()]
+        print(f"cpw={cpw} {name:18s}: evaluate bad cols {bad}  roundtrip bad cols {badi}")

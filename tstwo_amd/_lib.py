@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtstwo_hip.so")
+LIB_PATH = os.environ.get("TSTWO_HIP_LIB") or os.path.join(HERE, "libtstwo_hip.so")
 P = 2147483647
 
 

@@ -349,9 +349,12 @@ int launch_pass(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
 
 u32 pick_cols_per_wg(size_t tiles, size_t cnt) {
     // columns per workgroup: amortise the twiddle staging, but keep >= ~8 workgroups per CU in the grid
-    u32 cpw = 8;   // measured 32 x 2^22: 747 / 703 / 678 / 671 / 672 us for 1 / 2 / 4 / 8 / 16 columns per workgroup
-    { const char *e = getenv("TSTWO_CFFT_CPW"); if (e && atoi(e) > 0) cpw = (u32)atoi(e); }
-    while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)ctx().n_cus * 8) cpw >>= 1;
+    // (measured 32 x 2^22: 747 / 703 / 678 / 671 / 672 us for 1 / 2 / 4 / 8 / 16 columns per workgroup)
+    u32 cpw = 8;
+    const char *e = getenv("TSTWO_CFFT_CPW");            // debugging / tuning override, taken as is
+    if (e && atoi(e) > 0) cpw = (u32)atoi(e);
+    else
+        while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)ctx().n_cus * 8) cpw >>= 1;
     if (cpw > cnt) cpw = (u32)cnt;
     return cpw;
 }
@@ -376,6 +379,7 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds_bytes, c.stream, cp, (u32)cnt, cpw, args...);
     }
     TSTWO_LAUNCH_CHECK();
+    if (getenv("TSTWO_CFFT_SYNC")) TSTWO_HIP(hipStreamSynchronize(c.stream));
     return TSTWO_OK;
 }
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
 // ------------------------------------------------------------------------------------------------
 // Bottom pass: layers 0..12 (circle layer included) of a contiguous 2^13-word tile.
 template <bool INV>
-__global__ void __launch_bounds__(512, 8) k_cfft_b13(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
+__global__ void __launch_bounds__(512, 6) k_cfft_b13(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
                                                  const u32 *__restrict__ tw_end, u32 scale) {
     constexpr int LOGT = 13, THREADS = 512;
     constexpr u32 T = 1u << LOGT, QT = T / 4;
@@ -255,6 +255,7 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
             }
         }
     }
+    if constexpr (INV && R > 0) lds_barrier();   // the inverse reads the heap in its first stage, before any other barrier
     u32 ta, tb0 = 0, tb1 = 0;
     {
         const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 1))) + (ptrdiff_t)hi];
