@@ -172,6 +172,15 @@ int main() {
     printf(", \"m31_butterfly_T_per_s\": %.3f", lanes * ITERS * 8 / (ms * 1e-3) / 1e12);
     ms = time_ms([&] { hipLaunchKernelGGL(k_blake2s, dim3(blocks), dim3(256), 0, 0, out, 3u, 256); }, 20);
     printf(", \"blake2s_compress_G_per_s\": %.2f", lanes * 256 / (ms * 1e-3) / 1e9);
+    {   // same work shape as the Merkle leaf kernel: 2^22 lanes x 2 compressions, ~0.25 ms per launch
+        u32 *big;
+        CHECK(hipMalloc(&big, (size_t)4 << 22));
+        ms = time_ms([&] { hipLaunchKernelGGL(k_blake2s, dim3((1 << 22) / 256), dim3(256), 0, 0, big, 3u, 2); }, 20);
+        printf(", \"blake2s_compress_short_kernel_G_per_s\": %.2f", (double)(1 << 22) * 2 / (ms * 1e-3) / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_blake2s, dim3((1 << 21) / 256), dim3(256), 0, 0, big, 3u, 4); }, 20);
+        printf(", \"blake2s_compress_short_kernel_4per_G_per_s\": %.2f", (double)(1 << 21) * 4 / (ms * 1e-3) / 1e9);
+        hipFree(big);
+    }
     // HBM streaming: 2 GiB buffers (>> 256 MiB Infinity Cache)
     size_t bytes = (size_t)2 << 30;
     uint4 *a, *b;

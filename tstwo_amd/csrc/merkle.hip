@@ -9,6 +9,7 @@
 // prices it against the integer-issue ceiling as well as the HBM roofline the bench reports.
 // Algorithmic bytes for a layer of n nodes: 4*C*n (+ 64*n children) read, 32*n written.
 #include "common.h"
+#include <stdlib.h>
 
 using namespace tstwo;
 
@@ -145,6 +146,72 @@ __global__ void __launch_bounds__(256) k_merkle_layer(const uint4 *__restrict__ 
 #undef MERKLE_STEP
 }
 
+// ---- lean special cases of k_merkle_layer (same results, fewer non-hash instructions per compression) ----
+// (1) bottom layer whose column count is exactly 16*NBLK (e.g. the 32-column trace shard): every message word has
+//     a compile-time column index, so the column pointers are fetched once (scalar registers) instead of a
+//     clamp + scalar load + select per word per block.
+template <int NBLK>
+__global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, uint4 *__restrict__ out, size_t n_nodes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 rows = (u32)((n_nodes + stride - 1) / stride);
+    const size_t last_node = n_nodes - 1;
+    u32 cur[16], nxt[16];
+    {
+        const size_t nc = min(node0, last_node);
+#pragma unroll
+        for (int k = 0; k < 16; k++) cur[k] = cols.p[k][nc];
+    }
+    for (u32 j = 0; j < rows; j++) {
+        const size_t node = node0 + (size_t)j * stride;
+        const size_t nn = min(node + stride, last_node);          // next node of this lane (clamped: loads are never branched around)
+        const size_t nc = min(node, last_node);
+        u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            // fetch the next 64-byte block (next block of this node, or block 0 of the lane's next node) while this one is compressed
+            const int bn = (b + 1) % NBLK;
+            const size_t src = (b + 1 < NBLK) ? nc : nn;
+#pragma unroll
+            for (int k = 0; k < 16; k++) nxt[k] = cols.p[16 * bn + k][src];
+            b2s_compress(h, cur, 64u * (b + 1), b == NBLK - 1);
+#pragma unroll
+            for (int k = 0; k < 16; k++) cur[k] = nxt[k];
+        }
+        if (node < n_nodes) {
+            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
+            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+    }
+}
+
+// (2) inner layer without columns: node = Blake2s(left || right), one 64-byte block.
+__global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ prev, uint4 *__restrict__ out, size_t n_nodes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 rows = (u32)((n_nodes + stride - 1) / stride);
+    const size_t last_node = n_nodes - 1;
+    uint4 c[4], cn[4];
+    {
+        const uint4 *p = prev + 4 * min(node0, last_node);
+        c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
+    }
+    for (u32 j = 0; j < rows; j++) {
+        const size_t node = node0 + (size_t)j * stride;
+        const uint4 *pn = prev + 4 * min(node + stride, last_node);
+        cn[0] = pn[0]; cn[1] = pn[1]; cn[2] = pn[2]; cn[3] = pn[3];
+        u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+        const u32 m[16] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w,
+                           c[2].x, c[2].y, c[2].z, c[2].w, c[3].x, c[3].y, c[3].z, c[3].w};
+        b2s_compress(h, m, 64u, true);
+        if (node < n_nodes) {
+            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
+            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        c[0] = cn[0]; c[1] = cn[1]; c[2] = cn[2]; c[3] = cn[3];
+    }
+}
+
 // Several column-free levels per launch: a workgroup of WG lanes owns 2*WG consecutive nodes of layer `log_child`
 // and produces the WG, WG/2, ... nodes above them (LEVELS levels), exchanging digests through LDS.  Every level is
 // still written to its place in the layers buffer (MerkleProver keeps all layers, vcs/prover.ts:24-29).
@@ -223,6 +290,23 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
     unsigned blocks = ceil_div(n_nodes, 256);
     const unsigned cap = (unsigned)c.n_cus * 8 * 4;        // 8 workgroups per CU x 4 nodes per lane before grid-striding more
     if (blocks > cap) blocks = cap;
+    if (!prev && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !getenv("TSTWO_MERKLE_GENERIC")) {
+        HashColPtrs hp;
+        for (size_t k = 0; k < n_cols; k++) hp.p[k] = cols[k];
+        switch (n_cols / 16) {
+            case 1: hipLaunchKernelGGL(k_merkle_leaf_static<1>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
+            case 2: hipLaunchKernelGGL(k_merkle_leaf_static<2>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
+            case 3: hipLaunchKernelGGL(k_merkle_leaf_static<3>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
+            default: hipLaunchKernelGGL(k_merkle_leaf_static<4>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
+        }
+        TSTWO_LAUNCH_CHECK();
+        return TSTWO_OK;
+    }
+    if (prev && n_cols == 0 && !getenv("TSTWO_MERKLE_GENERIC")) {
+        hipLaunchKernelGGL(k_merkle_inner, dim3(blocks), dim3(256), 0, c.stream, (const uint4 *)prev, (uint4 *)out, n_nodes);
+        TSTWO_LAUNCH_CHECK();
+        return TSTWO_OK;
+    }
     // columns are absorbed kMaxHashCols per launch; launch boundaries fall on 64-byte block boundaries
     size_t col_base = 0;
     bool first = true;
