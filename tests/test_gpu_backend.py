@@ -371,3 +371,70 @@ def test_merkle_decommit_large():
     values, dec = tree.decommit(queries, cols)
     T.MerkleVerifier(T.Blake2sMerkleHasher(), tree.root(), log_sizes).verify(queries, values, dec)
     assert len(dec.hashWitness) > 0 and all(len(h) == 32 for h in dec.hashWitness)
+
+
+# ---------------------------------------------------------------- fri.test.ts: FriProver.commit (real Merkle + channel wiring)
+def _secure_low_degree_eval(log_deg, log_blowup, seed):
+    """A SecureEvaluation of degree < 2^log_deg on the canonic domain of log size log_deg + log_blowup."""
+    domain = T.CanonicCoset(log_deg + log_blowup).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    polys = [T.HipCirclePoly(rand_column(seed + k, 1 << log_deg)) for k in range(4)]
+    evs = T.evaluate_polynomials(polys, domain, tw)
+    return T.SecureEvaluation(domain, T.SecureColumnByCoords([e.values for e in evs])), tw
+
+
+def test_fri_commit_low_degree_and_transcript():
+    """fri.test.ts (commit phase): a low-degree column folds down to a last layer within the degree bound; the
+    transcript (roots mixed, alphas drawn) and every layer are reproduced with the CPU oracle."""
+    LOG_DEG, BLOW = 8, 2
+    cfg = T.FriConfig(2, BLOW, 3)
+    col, tw = _secure_low_degree_eval(LOG_DEG, BLOW, 1000)
+    ch = T.Blake2sChannel()
+    prover = T.FriProver.commit(ch, cfg, [col], tw)
+    assert len(prover.last_layer_poly) == 1 << cfg.log_last_layer_degree_bound
+    n = LOG_DEG + BLOW
+    assert len(prover.inner_layers) == (n - 1) - (cfg.log_last_layer_degree_bound + BLOW)
+    # replay with the oracle
+    ch2 = T.Blake2sChannel()
+    src = col.values.to_numpy()
+    _, root = orc.merkle_commit(src, [n] * 4)
+    assert prover.first_layer.merkle_tree.root() == root
+    ch2.mix_root(root)
+    alpha = ch2.draw_felt()
+    half = col.domain.halfCoset.initial_index.value
+    cur = orc.fold_circle_into_line([np.zeros(1 << (n - 1), dtype=np.uint32)] * 4, src, n, half, alpha.tup())
+    k, coset_init = n - 1, half
+    for layer in prover.inner_layers:
+        for a, b in zip(layer.evaluation.values.to_numpy(), cur):
+            assert (a == b).all()
+        _, r = orc.merkle_commit(cur, [k] * 4)
+        assert layer.merkle_tree.root() == r
+        ch2.mix_root(r)
+        alpha = ch2.draw_felt()
+        cur = orc.fold_line(cur, k, coset_init, alpha.tup())
+        coset_init = (coset_init * 2) & 0x7FFFFFFF
+        k -= 1
+    ch2.mix_felts(prover.last_layer_poly)
+    assert ch.digest() == ch2.digest()
+
+
+def test_fri_commit_rejects_high_degree_and_bad_inputs():
+    cfg = T.FriConfig(2, 2, 3)
+    col, tw = _secure_low_degree_eval(9, 1, 2000)       # degree 2^9 on a log-10 domain: blowup 1 < config's 2
+    with pytest.raises(ValueError, match="invalid degree"):
+        T.FriProver.commit(T.Blake2sChannel(), cfg, [col], tw)
+    with pytest.raises(ValueError, match="no columns"):
+        T.FriProver.commit(T.Blake2sChannel(), cfg, [], tw)
+    good, tw2 = _secure_low_degree_eval(6, 2, 3000)
+    with pytest.raises(ValueError, match="column sizes not decreasing"):
+        T.FriProver.commit(T.Blake2sChannel(), cfg, [good, good], tw2)
+
+
+def test_fri_commit_two_columns_mixed_sizes():
+    """Two circle columns (log 10 and log 8): the smaller one is folded in when the line layer reaches its size."""
+    cfg = T.FriConfig(1, 2, 3)
+    big, tw = _secure_low_degree_eval(8, 2, 4000)
+    small, _ = _secure_low_degree_eval(6, 2, 5000)
+    prover = T.FriProver.commit(T.Blake2sChannel(), cfg, [big, small], tw)
+    assert len(prover.last_layer_poly) == 2
+    assert len(prover.first_layer.merkle_tree.layers) == 11

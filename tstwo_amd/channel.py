@@ -1,0 +1,77 @@
+"""Blake2sChannel — host-side mirror of the reference's Fiat-Shamir transcript (packages/core/src/channel/blake2.ts:25-224,
+vcs/blake2_merkle.ts:28-31).  O(1) hashes per protocol round: it stays on the host and only *receives* Merkle roots from
+the GPU path.  hashlib.blake2s = BLAKE2s-256 unkeyed (what @noble/hashes computes for the reference)."""
+from __future__ import annotations
+
+import hashlib
+
+from .fields import M31, P, QM31
+
+BLAKE_BYTES_PER_HASH = 32
+FELTS_PER_HASH = 8
+SECURE_EXTENSION_DEGREE = 4
+
+
+class Blake2sChannel:
+    def __init__(self):
+        self._digest = bytes(32)              # Blake2sHash default: all zeros (blake2.ts:42-49)
+        self.n_challenges = 0
+        self.n_sent = 0
+        self._base_queue = []
+
+    create = classmethod(lambda cls: cls())
+
+    def digest(self) -> bytes:
+        return self._digest
+
+    def _update_digest(self, d: bytes) -> None:   # blake2.ts:76-79: inc_challenges resets n_sent
+        self._digest = d
+        self.n_challenges += 1
+        self.n_sent = 0
+
+    # ---- mixing
+    def mix_root(self, root: bytes) -> None:       # Blake2sMerkleChannel.mix_root (vcs/blake2_merkle.ts:28-31)
+        self._update_digest(hashlib.blake2s(self._digest + root).digest())
+
+    def mix_felts(self, felts) -> None:            # blake2.ts:113-118 (QM31.into_slice: 4 LE u32 each)
+        h = hashlib.blake2s(self._digest)
+        for f in felts:
+            for v in f.tup():
+                h.update(int(v).to_bytes(4, "little"))
+        self._update_digest(h.digest())
+
+    def mix_u32s(self, data) -> None:              # blake2.ts:120-136
+        h = hashlib.blake2s(self._digest)
+        for w in data:
+            if not (0 <= int(w) < 2**32):
+                raise TypeError(f"Invalid u32 value: {w}")
+            h.update(int(w).to_bytes(4, "little"))
+        self._update_digest(h.digest())
+
+    def mix_u64(self, value: int) -> None:         # blake2.ts:138-148
+        if not (0 <= int(value) < 2**64):
+            raise TypeError(f"Invalid u64 value: {value}")
+        self.mix_u32s([int(value) & 0xFFFFFFFF, int(value) >> 32])
+
+    # ---- drawing
+    def draw_random_bytes(self) -> bytes:          # blake2.ts:211-223: H(digest || LE32(n_sent) padded to 32 bytes)
+        counter = self.n_sent.to_bytes(4, "little") + bytes(BLAKE_BYTES_PER_HASH - 4)
+        self.n_sent += 1
+        return hashlib.blake2s(self._digest + counter).digest()
+
+    def _draw_base_felts(self):                    # blake2.ts:158-175: retry until all 8 words < 2P
+        while True:
+            b = self.draw_random_bytes()
+            u32s = [int.from_bytes(b[4 * i:4 * i + 4], "little") for i in range(FELTS_PER_HASH)]
+            if all(x < 2 * P for x in u32s):
+                return [M31.reduce(x) for x in u32s]
+
+    def draw_felt(self) -> QM31:                   # blake2.ts:177-184
+        while len(self._base_queue) < SECURE_EXTENSION_DEGREE:
+            self._base_queue += self._draw_base_felts()
+        a = self._base_queue[:4]
+        del self._base_queue[:4]
+        return QM31.from_u32_unchecked(*[m.value for m in a])
+
+    def draw_felts(self, n: int):
+        return [self.draw_felt() for _ in range(n)]
