@@ -438,3 +438,42 @@ def test_fri_commit_two_columns_mixed_sizes():
     prover = T.FriProver.commit(T.Blake2sChannel(), cfg, [big, small], tw)
     assert len(prover.last_layer_poly) == 2
     assert len(prover.first_layer.merkle_tree.layers) == 11
+
+
+# ---------------------------------------------------------------- pcs/prover.ts (Rust comment): commitment tree over HipBackend
+def test_commitment_scheme_prover_roundtrip():
+    """TreeBuilder.extend_evals -> interpolate; commit -> evaluate on the blown-up domain + Merkle + mix_root; then a
+    decommit of queried rows verifies against the root.  Checked against the oracle end to end."""
+    LOG, BLOW = 8, 2
+    tw = T.precompute_twiddles(T.CanonicCoset(LOG + BLOW + 1).circleDomain().halfCoset)      # one tree serves every size
+    scheme = T.CommitmentSchemeProver(BLOW, tw)
+    trace_domain = T.CanonicCoset(LOG).circleDomain()
+    cols_np = [rand_column(6000 + c, 1 << LOG) for c in range(5)]
+    small_np = [rand_column(6100 + c, 1 << (LOG - 2)) for c in range(2)]
+    tb = scheme.tree_builder()
+    span = tb.extend_evals([T.HipCircleEvaluation(trace_domain, c) for c in cols_np])
+    assert span == (0, 0, 5)
+    tb.extend_evals([T.HipCircleEvaluation(T.CanonicCoset(LOG - 2).circleDomain(), c) for c in small_np])
+    ch = T.Blake2sChannel()
+    tb.commit(ch)
+    tree = scheme.trees[0]
+    # oracle replay: interpolate on the trace domain, evaluate on the extended domain, commit
+    def ext_eval(vals, log):
+        h = T.CanonicCoset(log).circleDomain().halfCoset.initial_index.value
+        otw, oitw = orc.precompute_twiddles(h, log - 1)
+        coeffs = orc.cfft_interpolate(vals, log, h, oitw, log - 1)
+        big = log + BLOW
+        hb = T.CanonicCoset(big).circleDomain().halfCoset.initial_index.value
+        otwb, _ = orc.precompute_twiddles(hb, big - 1, inverse=False)
+        ext = np.concatenate([coeffs, np.zeros((1 << big) - coeffs.size, dtype=np.uint32)])
+        return orc.cfft_evaluate(ext, big, hb, otwb, big - 1)
+    exp = [ext_eval(c, LOG) for c in cols_np] + [ext_eval(c, LOG - 2) for c in small_np]
+    for ev, e in zip(tree.evaluations, exp):
+        assert (ev.values.to_numpy() == e).all()
+    _, oroot = orc.merkle_commit(exp, [LOG + BLOW] * 5 + [LOG - 2 + BLOW] * 2)
+    assert scheme.roots() == [oroot]
+    ch2 = T.Blake2sChannel(); ch2.mix_root(oroot)
+    assert ch.digest() == ch2.digest()
+    queries = {LOG + BLOW: [3, 77, 500], LOG - 2 + BLOW: [0, 9]}
+    values, dec = tree.decommit(queries)
+    T.MerkleVerifier(T.Blake2sMerkleHasher(), oroot, [LOG + BLOW] * 5 + [LOG - 2 + BLOW] * 2).verify(queries, values, dec)

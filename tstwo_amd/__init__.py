@@ -12,6 +12,7 @@ from .circle import (CanonicCoset, CircleDomain, CirclePoint, CirclePointIndex, 
 from .fields import CM31, M31, P, QM31  # noqa: F401
 from .fri_prover import FriConfig, FriProver, line_interpolate  # noqa: F401
 from .fri import HipFriOps, decompose, fold_circle_into_line, fold_line  # noqa: F401
+from .pcs import CommitmentSchemeProver, CommitmentTreeProver, TreeBuilder  # noqa: F401
 from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureEvaluation, TwiddleTree,  # noqa: F401
                    evaluate_polynomials, interpolate_columns, precompute_twiddles)
 from .quotients import (ColumnSampleBatch, accumulate, accumulateQuotients, generate_secure_powers,  # noqa: F401
