@@ -145,6 +145,12 @@ size_t tstwo_merkle_layers_bytes(uint32_t max_log);
  * Results land contiguously in host_out (n_items * words words).  srcs / idx are host arrays.  Synchronises. */
 int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, uint32_t words, size_t n_items, uint32_t *host_out);
 
+/* ---------------------------------------------------------------- GrindOps (backend/cpu/grind.ts:31-42, proof_of_work.ts)
+ * Smallest nonce >= start_nonce such that Blake2sChannel.mix_u64(nonce) applied to a channel with digest `digest`
+ * yields a digest with at least pow_bits trailing zero bits (channel/blake2.ts:96-111: the first 16 digest bytes read
+ * as a little-endian u128).  The reference's sequential loop returns the same (first) nonce.  Synchronises. */
+int tstwo_grind_blake2s(const uint8_t digest[32], uint32_t pow_bits, uint64_t start_nonce, uint64_t *nonce_out);
+
 /* ---------------------------------------------------------------- QuotientOps
  * accumulateQuotients row loop (backend/cpu/quotients.ts:52-116,160-178) with the per-batch constants
  * computed by the wrapper (quotientConstants, quotients.ts:124-191; constraints.ts:117-128):

@@ -477,3 +477,25 @@ def test_commitment_scheme_prover_roundtrip():
     queries = {LOG + BLOW: [3, 77, 500], LOG - 2 + BLOW: [0, 9]}
     values, dec = tree.decommit(queries)
     T.MerkleVerifier(T.Blake2sMerkleHasher(), oroot, [LOG + BLOW] * 5 + [LOG - 2 + BLOW] * 2).verify(queries, values, dec)
+
+
+# ---------------------------------------------------------------- proof_of_work / backend/cpu/grind.ts
+@pytest.mark.parametrize("pow_bits", [0, 1, 8, 14, 20])
+def test_grind_matches_sequential_reference_loop(pow_bits):
+    ch = T.Blake2sChannel()
+    ch.mix_u64(0x1234 + pow_bits)
+    nonce = T.grind(ch, pow_bits)
+    c = ch.clone(); c.mix_u64(nonce)
+    assert c.trailing_zeros() >= pow_bits
+    if pow_bits <= 14:                       # the reference's loop (grind.ts:31-42) returns the first such nonce
+        n = 0
+        while True:
+            c = ch.clone(); c.mix_u64(n)
+            if c.trailing_zeros() >= pow_bits:
+                break
+            n += 1
+        assert nonce == n
+    else:                                    # minimality at 2^20 scale: no smaller nonce in a sampled window passes
+        for n in range(max(0, nonce - 2000), nonce):
+            c = ch.clone(); c.mix_u64(n)
+            assert c.trailing_zeros() < pow_bits

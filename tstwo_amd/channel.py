@@ -29,6 +29,15 @@ class Blake2sChannel:
         self.n_challenges += 1
         self.n_sent = 0
 
+    def clone(self) -> "Blake2sChannel":
+        c = Blake2sChannel()
+        c._digest, c.n_challenges, c.n_sent, c._base_queue = self._digest, self.n_challenges, self.n_sent, list(self._base_queue)
+        return c
+
+    def trailing_zeros(self) -> int:              # blake2.ts:96-111: first 16 bytes as a little-endian u128
+        v = int.from_bytes(self._digest[:16], "little")
+        return 128 if v == 0 else (v & -v).bit_length() - 1
+
     # ---- mixing
     def mix_root(self, root: bytes) -> None:       # Blake2sMerkleChannel.mix_root (vcs/blake2_merkle.ts:28-31)
         self._update_digest(hashlib.blake2s(self._digest + root).digest())
@@ -75,3 +84,25 @@ class Blake2sChannel:
 
     def draw_felts(self, n: int):
         return [self.draw_felt() for _ in range(n)]
+
+
+class HipGrindOps:
+    """GrindOps (backend/cpu/grind.ts:31-42): the nonce search runs on the GPU (embarrassingly parallel Blake2s), the
+    sequential reference loop returns the same first nonce."""
+
+    @staticmethod
+    def grind(channel: Blake2sChannel, pow_bits: int) -> int:
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib as L
+        L.ensure_init()
+        d = np.frombuffer(channel.digest(), dtype=np.uint8).copy()
+        out = C.c_uint64(0)
+        L.call("tstwo_grind_blake2s", d.ctypes.data_as(L.u8p), pow_bits, 0, C.byref(out))
+        return out.value
+
+
+def grind(channel: Blake2sChannel, pow_bits: int) -> int:
+    return HipGrindOps.grind(channel, pow_bits)

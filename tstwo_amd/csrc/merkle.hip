@@ -279,6 +279,25 @@ __global__ void __launch_bounds__(256) k_gather_words(const GatherItem *__restri
     out[i] = items[item].src[items[item].idx * words + w];
 }
 
+// Proof-of-work grind: lane i of a batch tests nonce base + i; digest' = Blake2s(digest || LE64(nonce)) is one 40-byte block.
+struct GrindDigest { u32 w[8]; };
+__global__ void __launch_bounds__(256) k_grind(GrindDigest d, u32 pow_bits, unsigned long long base, unsigned long long count,
+                                              unsigned long long *__restrict__ best) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long nonce = base + i;
+    u32 m[16] = {d.w[0], d.w[1], d.w[2], d.w[3], d.w[4], d.w[5], d.w[6], d.w[7], (u32)nonce, (u32)(nonce >> 32), 0, 0, 0, 0, 0, 0};
+    u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+    b2s_compress(h, m, 40u, true);
+    u32 tz = 0;                                   // trailing zeros of the first 16 bytes as a little-endian u128
+    if (h[0]) tz = __ffs(h[0]) - 1;
+    else if (h[1]) tz = 32 + __ffs(h[1]) - 1;
+    else if (h[2]) tz = 64 + __ffs(h[2]) - 1;
+    else if (h[3]) tz = 96 + __ffs(h[3]) - 1;
+    else tz = 128;
+    if (tz >= pow_bits) atomicMin(best, nonce);
+}
+
 int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size_t n_cols, uint8_t *out) {
     Context &c = ctx();
     if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");
@@ -348,6 +367,36 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
 extern "C" {
 
 size_t tstwo_merkle_layers_bytes(u32 max_log) { return 32u * (((size_t)2 << max_log) - 1); }
+
+int tstwo_grind_blake2s(const uint8_t digest[32], u32 pow_bits, uint64_t start_nonce, uint64_t *nonce_out) {
+    TSTWO_REQUIRE_READY();
+    if (!digest || !nonce_out) return set_error(TSTWO_ERR_BAD_ARG, "grind: null argument");
+    if (pow_bits > 128) return set_error(TSTWO_ERR_BAD_ARG, "grind: pow_bits > 128");
+    Context &c = ctx();
+    int rc = ensure_scratch(64);
+    if (rc) return rc;
+    unsigned long long *best = (unsigned long long *)c.scratch;
+    GrindDigest d;
+    for (int i = 0; i < 8; i++)
+        d.w[i] = (u32)digest[4 * i] | ((u32)digest[4 * i + 1] << 8) | ((u32)digest[4 * i + 2] << 16) | ((u32)digest[4 * i + 3] << 24);
+    unsigned long long base = start_nonce;
+    const unsigned long long none = ~0ull;
+    for (;;) {
+        // batches grow with the expected work so easy targets return after one small launch
+        unsigned long long batch = 1ull << 20;
+        if (base - start_nonce >= (1ull << 22)) batch = 1ull << 26;
+        if (none - base < batch) batch = none - base;
+        if (batch == 0) return set_error(TSTWO_ERR_BAD_ARG, "grind: nonce space exhausted");
+        TSTWO_HIP(hipMemcpyAsync(best, &none, sizeof(none), hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_grind, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, c.stream, d, pow_bits, base, batch, best);
+        TSTWO_LAUNCH_CHECK();
+        unsigned long long found = none;
+        TSTWO_HIP(hipMemcpyAsync(&found, best, sizeof(found), hipMemcpyDeviceToHost, c.stream));
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        if (found != none) { *nonce_out = found; return TSTWO_OK; }
+        base += batch;
+    }
+}
 
 int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, u32 words, size_t n_items, u32 *host_out) {
     TSTWO_REQUIRE_READY();
