@@ -1,0 +1,89 @@
+// ffi.ts — bun:ffi binding of libtstwo_hip.so (C ABI: include/tstwo_hip.h).
+//
+// Intended location in tstwo: packages/core/src/backend/hip/ffi.ts.  NOT TESTED in the build image (no Bun there);
+// the same ABI, call for call, is exercised by tstwo_amd/_lib.py (ctypes) in every `-m gpu` test of this repository.
+// Device pointers travel as u64 (bigint); `P` arguments are host typed arrays (ptr(...)).
+import { dlopen, FFIType, ptr } from "bun:ffi";
+
+const { i32, u32, u64, ptr: P, cstring } = FFIType;
+
+const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
+  tstwo_init: { args: [i32], returns: i32 },
+  tstwo_shutdown: { args: [], returns: i32 },
+  tstwo_last_error: { args: [], returns: cstring },
+  tstwo_sync: { args: [], returns: i32 },
+  tstwo_malloc: { args: [P, u64], returns: i32 },
+  tstwo_free: { args: [u64], returns: i32 },
+  tstwo_upload: { args: [u64, P, u64], returns: i32 },
+  tstwo_download: { args: [P, u64, u64], returns: i32 },
+  tstwo_copy: { args: [u64, u64, u64], returns: i32 },
+  tstwo_zero: { args: [u64, u64], returns: i32 },
+  tstwo_m31_add: { args: [u64, u64, u64, u64], returns: i32 },
+  tstwo_m31_sub: { args: [u64, u64, u64, u64], returns: i32 },
+  tstwo_m31_mul: { args: [u64, u64, u64, u64], returns: i32 },
+  tstwo_m31_neg: { args: [u64, u64, u64], returns: i32 },
+  tstwo_m31_batch_inverse: { args: [u64, u64, u64], returns: i32 },
+  tstwo_qm31_batch_inverse: { args: [P, P, u64], returns: i32 },
+  tstwo_qm31_mul: { args: [P, P, P, u64], returns: i32 },
+  tstwo_secure_accumulate: { args: [P, P, u64], returns: i32 },
+  tstwo_bit_reverse: { args: [P, u64, u64], returns: i32 },
+  tstwo_twiddles_build: { args: [u32, u32, u64, u64], returns: i32 },
+  tstwo_cfft_evaluate: { args: [P, u64, u32, u32, u64, u32], returns: i32 },
+  tstwo_cfft_interpolate: { args: [P, u64, u32, u32, u64, u32], returns: i32 },
+  tstwo_poly_extend: { args: [u64, u32, u64, u32], returns: i32 },
+  tstwo_eval_at_point: { args: [u64, u32, P, P, P], returns: i32 },
+  tstwo_fri_fold_line: { args: [P, u32, u64, u32, P, P], returns: i32 },
+  tstwo_fri_fold_line_tw: { args: [P, u32, u64, P, P], returns: i32 },
+  tstwo_fri_fold_circle_into_line: { args: [P, u64, P, u32, u64, u32, P], returns: i32 },
+  tstwo_fri_fold_circle_into_line_tw: { args: [P, u64, P, u32, u64, P], returns: i32 },
+  tstwo_fri_decompose: { args: [P, u64, P, P], returns: i32 },
+  tstwo_merkle_commit_layer: { args: [u32, u64, P, u64, u64], returns: i32 },
+  tstwo_merkle_commit: { args: [P, P, u64, u64, P], returns: i32 },
+  tstwo_gather_words: { args: [P, P, u32, u64, P], returns: i32 },
+  tstwo_grind_blake2s: { args: [P, u32, u64, P], returns: i32 },
+  tstwo_quotients_accumulate: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P, P, P, P], returns: i32 },
+});
+
+export const hip = lib.symbols;
+
+/** Throws with the reference's own error text ("0 has no inverse", "length is not power of two", ...). */
+export function check(rc: number): void {
+  if (rc !== 0) throw new Error(String(hip.tstwo_last_error()));
+}
+
+let initialised = false;
+export function ensureInit(): void {
+  if (!initialised) {
+    check(hip.tstwo_init(Number(process.env.LOCAL_RANK ?? 0)));   // one process per GPU
+    initialised = true;
+  }
+}
+
+/** An owned device allocation. */
+export class DeviceBuffer {
+  readonly dev: bigint;
+  constructor(readonly nbytes: number) {
+    ensureInit();
+    const out = new BigUint64Array(1);
+    check(hip.tstwo_malloc(ptr(out), BigInt(Math.max(nbytes, 16))));
+    this.dev = out[0]!;
+  }
+  upload(words: Uint32Array | Uint8Array, byteOffset = 0): void {
+    if (words.byteLength) check(hip.tstwo_upload(this.dev + BigInt(byteOffset), ptr(words), BigInt(words.byteLength)));
+  }
+  downloadU32(count: number, byteOffset = 0): Uint32Array {
+    const out = new Uint32Array(count);
+    if (count) check(hip.tstwo_download(ptr(out), this.dev + BigInt(byteOffset), BigInt(4 * count)));
+    return out;
+  }
+  downloadBytes(count: number, byteOffset = 0): Uint8Array {
+    const out = new Uint8Array(count);
+    if (count) check(hip.tstwo_download(ptr(out), this.dev + BigInt(byteOffset), BigInt(count)));
+    return out;
+  }
+  free(): void { check(hip.tstwo_free(this.dev)); }
+}
+
+export const ptrs = (devs: bigint[]): BigUint64Array => BigUint64Array.from(devs.length ? devs : [0n]);
+export const u32s = (vals: number[]): Uint32Array => Uint32Array.from(vals.length ? vals : [0]);
+export { ptr };
