@@ -50,7 +50,8 @@ int tstwo_device_name(char *buf, size_t buflen);
 int tstwo_set_stream(void *hip_stream);     /* borrow a caller stream (NULL = back to the library's) */
 int tstwo_sync(void);
 int tstwo_malloc(void **dev, size_t bytes);
-int tstwo_free(void *dev);
+int tstwo_free(void *dev);                   /* returns the block to the library's caching allocator (no sync) */
+int tstwo_trim(void);                        /* synchronises and gives every cached block back to HIP */
 int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);     /* synchronous */
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
 int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes);        /* async d2d */

@@ -499,3 +499,14 @@ def test_grind_matches_sequential_reference_loop(pow_bits):
         for n in range(max(0, nonce - 2000), nonce):
             c = ch.clone(); c.mix_u64(n)
             assert c.trailing_zeros() < pow_bits
+
+
+def test_line_interpolate_with_and_without_tree():
+    """lineIfft x^-1 from the inverse twiddle tree == the reference's per-element domain.at(i).inverse()."""
+    k = 5
+    tw = T.precompute_twiddles(T.Coset.half_odds(8))
+    coset = T.Coset.half_odds(8).repeated_double(3)
+    ev = T.LineEvaluation(T.LineDomain(coset), T.SecureColumnByCoords.from_numpy([rand_column(7000 + c, 1 << k) for c in range(4)]))
+    a = T.line_interpolate(ev, tw)
+    b = T.line_interpolate(ev, None)
+    assert [x.tup() for x in a] == [x.tup() for x in b]

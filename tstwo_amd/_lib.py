@@ -38,6 +38,7 @@ _SIGS = {
     "tstwo_sync": [],
     "tstwo_malloc": [C.POINTER(vp), C.c_size_t],
     "tstwo_free": [vp],
+    "tstwo_trim": [],
     "tstwo_upload": [vp, vp, C.c_size_t],
     "tstwo_download": [vp, vp, C.c_size_t],
     "tstwo_copy": [vp, vp, C.c_size_t],

@@ -285,16 +285,16 @@ __global__ void k_cfft_small(ColPtrs cols, u32 n_cols, u32 n, u32 tx, u32 ty, u3
 }
 
 struct Pass { u32 lo, k, c; };
-// passes low -> high
-int plan_passes(u32 n, Pass *out) {
+// passes low -> high.  kb = layers of the bottom pass (contiguous tile), the rest is cut into strided passes of <= ka_max.
+int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA) {
     int cnt = 0;
-    if (n <= kMaxLogTileB) {
+    if (n <= kb) {
         out[cnt++] = {0, n, 0};
         return cnt;
     }
-    out[cnt++] = {0, kMaxLogTileB, 0};
-    u32 rem = n - kMaxLogTileB, lo = kMaxLogTileB;
-    u32 np = (rem + kMaxKA - 1) / kMaxKA;
+    out[cnt++] = {0, kb, 0};
+    u32 rem = n - kb, lo = kb;
+    u32 np = (rem + ka_max - 1) / ka_max;
     u32 base = rem / np, extra = rem % np;
     for (u32 s = 0; s < np; s++) {
         u32 k = base + (s < extra ? 1 : 0);
@@ -393,8 +393,14 @@ int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, 
 template <bool INV>
 int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u32 *tw_end, u32 scale) {
     if (ps.lo == 0) {
-        const size_t tiles = (size_t)1 << (n - 13);
-        return launch_fast_kernel(fast::k_cfft_b13<INV>, 512, ((size_t)(1 << 13) + (1 << 8) + 512) * sizeof(u32), tiles, cols, n_cols, n, tw_end, scale);
+        const size_t tiles = (size_t)1 << (n - ps.k);
+        const size_t lds = (((size_t)1 << ps.k) + ((size_t)1 << (ps.k - 5)) + ((size_t)1 << (ps.k - 4))) * sizeof(u32);
+        switch (ps.k) {
+            case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale);
+            case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale);
+            case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale);
+            default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported bottom pass");
+        }
     }
     switch (ps.k) {
         case 1: return launch_a<INV, 1>(cols, n_cols, n, ps.lo, tw_end, scale);
@@ -406,6 +412,7 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         case 7: return launch_a<INV, 7>(cols, n_cols, n, ps.lo, tw_end, scale);
         case 8: return launch_a<INV, 8>(cols, n_cols, n, ps.lo, tw_end, scale);
         case 9: return launch_a<INV, 9>(cols, n_cols, n, ps.lo, tw_end, scale);
+        case 10: return launch_a<INV, 10>(cols, n_cols, n, ps.lo, tw_end, scale);
         default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
     }
 }
@@ -441,7 +448,13 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
     if (tw_log > 31 || ((size_t)1 << (n - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     Pass passes[8];
-    int np = plan_passes(n, passes);
+    u32 kb = kMaxLogTileB, ka_max = kMaxKA;
+    {   // tuning knobs (experiments): bottom-pass size 11..13, strided-pass limit 9..11
+        const char *e1 = getenv("TSTWO_CFFT_KB"), *e2 = getenv("TSTWO_CFFT_KA");
+        if (e1 && atoi(e1) >= 11 && atoi(e1) <= 13) kb = (u32)atoi(e1);
+        if (e2 && atoi(e2) >= 1 && atoi(e2) <= 10) ka_max = (u32)atoi(e2);
+    }
+    int np = n >= kMaxLogTileB ? plan_passes(n, passes, kb, ka_max) : plan_passes(n, passes);
     for (size_t i = 0; i < n_cols; i++)
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
     if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");

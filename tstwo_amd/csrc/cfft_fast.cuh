@@ -2,7 +2,7 @@
 //
 // Geometry is compile-time so that addressing folds into immediates and the register budget stays
 // near 64 VGPRs (8 waves/SIMD): every lane owns 16 words of the tile.
-//   k_cfft_b13<INV>     bottom pass: layers 0..12 on a contiguous 2^13-word tile, 512 lanes.
+//   k_cfft_b<INV, LOGT> bottom pass: layers 0..LOGT-1 on a contiguous 2^LOGT-word tile (LOGT = 13: 512 lanes).
 //   k_cfft_a<INV, K>    strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^(14-K) words, 1024 lanes.
 // Structure of one tile (forward; the inverse mirrors it):
 //   1. the tile arrives as four 16-byte loads per lane a quarter-tile apart, so the pass's two top layers
@@ -95,14 +95,16 @@ __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bottom pass: layers 0..12 (circle layer included) of a contiguous 2^13-word tile.
-template <bool INV>
-__global__ void __launch_bounds__(512, 6) k_cfft_b13(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
+// Bottom pass: layers 0..LOGT-1 (circle layer included) of a contiguous 2^LOGT-word tile, LOGT in 11..13
+// (2^(LOGT-4) lanes).  LOGT = 13 is the default; smaller tiles give more workgroups when there are few columns.
+template <bool INV, int LOGT>
+__global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
                                                  const u32 *__restrict__ tw_end, u32 scale) {
-    constexpr int LOGT = 13, THREADS = 512;
+    constexpr int THREADS = 1 << (LOGT - 4);
+    constexpr int GM = LOGT - 10;              // layers of the middle LDS stage (bits [8, LOGT-2))
     constexpr u32 T = 1u << LOGT, QT = T / 4;
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
-    u32 *twl = lds + T + T / 32;                          // 512-entry heap: layer bits 4..10
+    u32 *twl = lds + T + T / 32;                          // 2^(LOGT-4)-entry heap: layer bits 4..LOGT-3
     const u32 t = threadIdx.x;
     const u32 groups = (n_cols + cols_per_wg - 1) / cols_per_wg;
     const u32 hi = blockIdx.x / groups;                   // tile index
@@ -113,25 +115,25 @@ __global__ void __launch_bounds__(512, 6) k_cfft_b13(ColPtrs cols, u32 n_cols, u
     // twiddles of this lane's 16-word run for layers 1..3 (registers, doubled); layer 0 reuses layer 1's
     u32 t1[4], t2[2], t3;
     {
-        const uint4 q1 = *reinterpret_cast<const uint4 *>(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << 11) + 4 * t);
-        const uint2 q2 = *reinterpret_cast<const uint2 *>(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << 10) + 2 * t);
-        const u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << 9) + t)];
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)) + 4 * t);
+        const uint2 q2 = *reinterpret_cast<const uint2 *>(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)) + 2 * t);
+        const u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << (LOGT - 4)) + t)];
         t1[0] = q1.x + q1.x; t1[1] = q1.y + q1.y; t1[2] = q1.z + q1.z; t1[3] = q1.w + q1.w;
         t2[0] = q2.x + q2.x; t2[1] = q2.y + q2.y;
         t3 = q3 + q3;
     }
-    // heap: level lv in 2..8 holds layer bit b = 12 - lv
+    // heap: level lv in 2..LOGT-5 holds layer bit b = LOGT-1 - lv
     if (t >= 4) {
         const u32 lv = 31u - (u32)__clz(t);
-        const u32 b = 12u - lv;
+        const u32 b = (u32)(LOGT - 1) - lv;
         const u32 v = tw_end[-(ptrdiff_t)((size_t)1 << (n - b)) + (ptrdiff_t)(((size_t)hi << lv) + (t - (1u << lv)))];
         twl[t] = v + v;
     }
-    u32 ta, tb0, tb1;                                      // layer 12 / layer 11 twiddles (wave-uniform)
+    u32 ta, tb0, tb1;                                      // layer LOGT-1 / LOGT-2 twiddles (wave-uniform)
     {
-        const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - 12)) + (ptrdiff_t)hi];
-        const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 11)) + (ptrdiff_t)(2 * (size_t)hi)];
-        const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 11)) + (ptrdiff_t)(2 * (size_t)hi + 1)];
+        const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 1))) + (ptrdiff_t)hi];
+        const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
+        const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
         ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
     }
 
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(512, 6) k_cfft_b13(ColPtrs cols, u32 n_cols, u
         u32 *__restrict__ data = cols.p[col] + base;
         const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
         if (!INV) {
-            top_layers<false, true>(pf, ta, tb0, tb1);                    // layers 12, 11
+            top_layers<false, true>(pf, ta, tb0, tb1);                    // layers LOGT-1, LOGT-2
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(512, 6) k_cfft_b13(ColPtrs cols, u32 n_cols, u
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + 4 * t + j * QT);
-            lds_stage<3, 8, LOGT, THREADS, false>(lds, twl);               // layers 10..8
+            lds_stage<GM, 8, LOGT, THREADS, false>(lds, twl);              // layers LOGT-3..8
             lds_barrier();
             lds_stage<4, 4, LOGT, THREADS, false>(lds, twl);               // layers 7..4
             lds_barrier();
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(512, 6) k_cfft_b13(ColPtrs cols, u32 n_cols, u
             for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + 16 * t + 4 * j);
             lds_stage<4, 4, LOGT, THREADS, true>(lds, twl);
             lds_barrier();
-            lds_stage<3, 8, LOGT, THREADS, true>(lds, twl);
+            lds_stage<GM, 8, LOGT, THREADS, true>(lds, twl);
             lds_barrier();
             uint4 x[4];
 #pragma unroll

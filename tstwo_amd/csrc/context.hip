@@ -1,7 +1,12 @@
 // context.hip — lifecycle, device memory, stream and event plumbing of the C ABI (include/tstwo_hip.h).
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include <map>
+#include <unordered_map>
+#include <vector>
 
 namespace tstwo {
 
@@ -66,6 +71,23 @@ static u32 h_sub(u32 a, u32 b) { return a >= b ? a - b : a + M31_P - b; }
 
 using namespace tstwo;
 
+namespace {
+struct Pool {
+    std::map<size_t, std::vector<void *>> free_lists;     // size class -> cached blocks
+    std::unordered_map<void *, size_t> live;               // block -> size class
+    size_t cached_bytes = 0;
+    bool enabled = true, probed = false;
+};
+Pool g_pool;
+size_t size_class(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    size_t p = 4096;
+    while (p < bytes) p <<= 1;                            // 2^k ...
+    if (bytes <= (p >> 1) + (p >> 2)) return (p >> 1) + (p >> 2);   // ... or 1.5 * 2^(k-1): at most 33 % slack
+    return p;
+}
+}  // namespace
+
 extern "C" {
 
 const char *tstwo_last_error(void) { return g_last_error.c_str(); }
@@ -120,6 +142,9 @@ int tstwo_shutdown(void) {
     Context &c = g_ctx;
     if (!c.ready) return TSTWO_OK;
     (void)hipStreamSynchronize(c.stream);
+    (void)tstwo_trim();
+    for (auto &kv : g_pool.live) (void)hipFree(kv.first);
+    g_pool.live.clear();
     if (c.gen_pow2) (void)hipFree(c.gen_pow2);
     if (c.flag) (void)hipFree(c.flag);
     if (c.scratch) (void)hipFree(c.scratch);
@@ -149,17 +174,60 @@ int tstwo_sync(void) {
     return TSTWO_OK;
 }
 
+// Caching device allocator.  Wrappers allocate a result column per operation (value semantics of the reference's
+// Column API) and a raw hipMalloc / hipFree pair per call costs more than most kernels, so freed blocks are kept in
+// size-class free lists and handed out again.  Every use of device memory by this library is ordered on one stream
+// (kernels, memsets, copies), so a block released after operation k and reused by operation k+1 needs no host
+// synchronisation: k+1 cannot start before k has finished.  Blocks return to HIP at tstwo_shutdown / tstwo_trim.
+
+int tstwo_trim(void) {
+    if (!g_ctx.ready) return TSTWO_OK;
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    for (auto &kv : g_pool.free_lists)
+        for (void *p : kv.second) (void)hipFree(p);
+    g_pool.free_lists.clear();
+    g_pool.cached_bytes = 0;
+    return TSTWO_OK;
+}
+
 int tstwo_malloc(void **dev, size_t bytes) {
     TSTWO_REQUIRE_READY();
     if (!dev) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_malloc: null out pointer");
     *dev = nullptr;
+    if (!g_pool.probed) { g_pool.probed = true; g_pool.enabled = getenv("TSTWO_NO_POOL") == nullptr; }
     if (bytes == 0) bytes = 16;
-    TSTWO_HIP(hipMalloc(dev, bytes));
+    const size_t cls = g_pool.enabled ? size_class(bytes) : bytes;
+    if (g_pool.enabled) {
+        auto it = g_pool.free_lists.find(cls);
+        if (it != g_pool.free_lists.end() && !it->second.empty()) {
+            *dev = it->second.back();
+            it->second.pop_back();
+            g_pool.cached_bytes -= cls;
+            g_pool.live[*dev] = cls;
+            return TSTWO_OK;
+        }
+    }
+    hipError_t e = hipMalloc(dev, cls);
+    if (e != hipSuccess && g_pool.cached_bytes) {           // out of memory with blocks cached: give them back and retry
+        (void)hipGetLastError();
+        int rc = tstwo_trim();
+        if (rc) return rc;
+        e = hipMalloc(dev, cls);
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    if (g_pool.enabled) g_pool.live[*dev] = cls;
     return TSTWO_OK;
 }
 int tstwo_free(void *dev) {
     if (!dev) return TSTWO_OK;
     TSTWO_REQUIRE_READY();
+    auto it = g_pool.live.find(dev);
+    if (it != g_pool.live.end()) {
+        g_pool.free_lists[it->second].push_back(dev);
+        g_pool.cached_bytes += it->second;
+        g_pool.live.erase(it);
+        return TSTWO_OK;
+    }
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
     TSTWO_HIP(hipFree(dev));
     return TSTWO_OK;

@@ -38,17 +38,28 @@ class FriConfig:
         channel.mix_u64(self.log_last_layer_degree_bound)
 
 
-def line_interpolate(evaluation: LineEvaluation) -> list:
+def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = None) -> list:
     """LineEvaluation.interpolate + lineIfft (poly/line.ts:312-390) on the host: the last FRI layer has at most
-    2^(log_last_layer_degree_bound + log_blowup_factor) elements.  Returns bit-reversed-order coefficients."""
+    2^(log_last_layer_degree_bound + log_blowup_factor) elements.  Returns bit-reversed-order coefficients.
+    The x^-1 of each level are read from the tail of the inverse twiddle tree when the domain is a doubling of its
+    root (level of log size k = 2^(k-1) entries, bit-reversed); otherwise they are computed per element like the reference."""
     vals = evaluation.values.to_vec()
     n = len(vals)
     log_n = n.bit_length() - 1
     vals = [vals[bit_reverse_index(i, log_n)] for i in range(n)]
     domain = evaluation.domain()
+    tail = None
+    if twiddles is not None and log_n >= 1 and domain.coset().is_doubling_of(twiddles.rootCoset):
+        L_ = twiddles.itwiddles.len()
+        tail = twiddles.itwiddles.buf.download(count=n, offset=4 * (L_ - n))        # last n entries of the tree
     while domain.size() > 1:
         size, half = domain.size(), domain.size() // 2
-        inv = [domain.at(i).inverse() for i in range(half)]
+        k = domain.logSize()
+        if tail is not None:
+            seg = tail[n - size:n - half]                                            # tree[L - 2^k : L - 2^(k-1)]
+            inv = [M31(int(seg[bit_reverse_index(i, k - 1)])) for i in range(half)]
+        else:
+            inv = [domain.at(i).inverse() for i in range(half)]
         for start in range(0, n, size):
             for i in range(half):
                 a, b = vals[start + i], vals[start + i + half]
@@ -104,7 +115,7 @@ class FriProver:
         # last layer (fri.ts:718-754)
         if layer_eval.len() != config.last_layer_domain_size():
             raise ValueError("last layer domain size mismatch")
-        coeffs_br = line_interpolate(layer_eval)
+        coeffs_br = line_interpolate(layer_eval, twiddles)
         log_n = len(coeffs_br).bit_length() - 1
         ordered = [coeffs_br[bit_reverse_index(i, log_n)] for i in range(len(coeffs_br))]   # intoOrderedCoefficients
         bound = 1 << config.log_last_layer_degree_bound
