@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 
 LOG_SIZE = 22
 COLS_PER_GPU = 32
+VALU_PER_BUTTERFLY = 11.6      # measured: (115.3M + 153.2M wave instr) * 64 / (32 cols * 22 layers * 2^21)
+VALU_PEAK = 256 * 4 * 16 * 2.4e9
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -200,7 +202,7 @@ def main():
         total_elems = world * n_cols * N * steps
         cfft_ms = t_cfft / steps
         merkle_ms = t_merkle / steps
-        # dominant kernel: the CFFT pass kernels (k_cfft_a<K>, k_cfft_b13), (passes) launches per step over all columns.
+        # dominant kernel: the CFFT pass kernels (fast::k_cfft_a<INV,K>, fast::k_cfft_b<INV,LOGT>), (passes) launches per step over all columns.
         passes = 1 if n <= 13 else 1 + -(-(n - 13) // 9)
         algo_bytes_transform = 8.0 * N * n_cols                     # 8*N per column transform
         algo_bytes_launch = algo_bytes_transform / passes
@@ -237,10 +239,16 @@ def main():
             "merkle_ms": merkle_ms,
             "merkle_GBps": merkle_bytes / (merkle_ms * 1e-3) / 1e9,
             "merkle_frac_of_hbm_peak": merkle_bytes / (merkle_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9> + fast::k_cfft_b13<false> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9> + fast::k_cfft_b<false,13> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "launches_per_step": passes, "avg_launch_ms": launch_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch},
+                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         # the kernel is VALU-bound, so the lane-op rate is reported next to the HBM fraction.
+                         # 11.2-12.2 VALU instructions per butterfly (profiles/r01_cfft_sq_counters.json), 39.3e12 lane-ops/s
+                         # = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz.
+                         "valu": {"instr_per_butterfly": VALU_PER_BUTTERFLY, "peak_lane_ops_per_s": VALU_PEAK,
+                                  "achieved_lane_ops_per_s": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3),
+                                  "frac": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK}},
             "device": L.device_name(),
         }
         if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE:

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import P, ROOT, load_vectors
+from conftest import P, ROOT, load_vectors, rand_column
 from oracle import oracle as orc
 
 import tstwo_amd as T
@@ -192,3 +192,77 @@ def test_blake2s_channel_mirror():
     assert cfg.last_layer_domain_size() == 8 and cfg.security_bits() == 3
     with pytest.raises(ValueError):
         T.FriConfig(11, 1, 3)
+
+
+# ---------------------------------------------------------------- fri.test.ts "FRI Implementation" host-only pieces
+def test_fri_host_sparse_evaluation_and_rebuild():
+    from tstwo_amd.fri_verifier import (InsufficientWitnessError, SparseEvaluation, accumulate_line,
+                                        compute_decommitment_positions_and_rebuild_evals)
+    q = lambda v: T.QM31.from_(T.M31(v))
+    s = SparseEvaluation([[T.QM31.one()] * 2, [T.QM31.zero()] * 2], [0, 1])
+    assert len(s.subset_evals) == 2 and len(s.subset_domain_initial_indexes) == 2
+    with pytest.raises(ValueError, match=r"All subset evaluations must have length equal to 2\^FOLD_STEP"):
+        SparseEvaluation([[T.QM31.one()], [T.QM31.zero(), T.QM31.one()]], [0, 1])
+    with pytest.raises(ValueError, match="Number of subset evaluations must match number of domain indexes"):
+        SparseEvaluation([[T.QM31.one()] * 2], [0, 1])
+    # rebuild: queries 0 and 2 of a log-2 domain, witnesses fill positions 1 and 3
+    pos, sp = compute_decommitment_positions_and_rebuild_evals(T.Queries([0, 2], 2), [q(1), q(3)], iter([q(2), q(4)]), 1)
+    assert pos == [0, 1, 2, 3]
+    assert [[e.tup()[0] for e in ev] for ev in sp.subset_evals] == [[1, 2], [3, 4]]
+    assert sp.subset_domain_initial_indexes == [0, 1]            # bit_reverse(0, 2), bit_reverse(2, 2)
+    with pytest.raises(InsufficientWitnessError):
+        compute_decommitment_positions_and_rebuild_evals(T.Queries([0, 2], 2), [q(1), q(3)], iter([]), 1)
+    layer, colv, alpha = [q(1), q(2)], [q(3), q(4)], q(5)
+    accumulate_line(layer, colv, alpha)
+    assert [e.tup()[0] for e in layer] == [1 * 25 + 3, 2 * 25 + 4]
+
+
+def test_fri_host_degree_bounds_and_config():
+    assert T.CirclePolyDegreeBound(7).fold_to_line().log_degree_bound == 6
+    b = T.LinePolyDegreeBound(5)
+    assert b.fold(2).log_degree_bound == 3 and b.fold(6) is None
+    cfg = T.FriConfig(3, 2, 10)
+    assert cfg.last_layer_domain_size() == 1 << 5 and cfg.security_bits() == 20
+    with pytest.raises(ValueError):
+        T.FriConfig(11, 2, 1)
+    with pytest.raises(ValueError):
+        T.FriConfig(1, 0, 1)
+
+
+def test_fri_host_sparse_fold_matches_oracle():
+    """SparseEvaluation.fold_line / fold_circle of one 2-element coset == the oracle's fold of the whole layer at that index."""
+    n = 5
+    cols = [rand_column(900 + k, 1 << n) for k in range(4)]
+    alpha = T.QM31.from_u32_unchecked(19283, 1, 2, 3)
+    from tstwo_amd.fri_verifier import SparseEvaluation
+    from tstwo_amd.circle import bit_reverse_index
+    at = lambda i: T.QM31.from_u32_unchecked(*(int(c[i]) for c in cols))
+    # line layer on half_odds(n)
+    dom = T.LineDomain(T.Coset.half_odds(n))
+    folded = orc.fold_line(cols, n, dom.coset().initial_index.value, alpha.tup())
+    for pair in (0, 3, 9, 15):
+        s = SparseEvaluation([[at(2 * pair), at(2 * pair + 1)]], [bit_reverse_index(2 * pair, n)])
+        assert s.fold_line(alpha, dom)[0].tup() == tuple(int(c[pair]) for c in folded)
+    # circle layer on CanonicCoset(n)
+    cd = T.CanonicCoset(n).circleDomain()
+    zero = [np.zeros(1 << (n - 1), dtype=np.uint32)] * 4
+    foldc = orc.fold_circle_into_line(zero, cols, n, cd.halfCoset.initial_index.value, alpha.tup())
+    for pair in (0, 5, 12):
+        s = SparseEvaluation([[at(2 * pair), at(2 * pair + 1)]], [bit_reverse_index(2 * pair, n)])
+        assert s.fold_circle(alpha, cd)[0].tup() == tuple(int(c[pair]) for c in foldc)
+
+
+def test_line_poly_host():
+    """line.test.ts: ordered <-> bit-reversed coefficients; eval_at_point = sum c_k * basis_k(x) with pi(x) = 2x^2 - 1."""
+    co = [T.QM31.from_u32_unchecked(k + 1, 2 * k, 3, k * k) for k in range(8)]
+    p = T.LinePoly.from_ordered_coefficients(co)
+    assert [c.tup() for c in p.into_ordered_coefficients()] == [c.tup() for c in co]
+    x = T.QM31.from_u32_unchecked(5, 6, 7, 8)
+    pi = lambda v: v.square().double().sub(T.QM31.one())
+    basis = [T.QM31.one(), x, pi(x), x.mul(pi(x)), pi(pi(x)), x.mul(pi(pi(x))), pi(x).mul(pi(pi(x))), x.mul(pi(x)).mul(pi(pi(x)))]
+    want = T.QM31.zero()
+    for c, b in zip(co, basis):
+        want = want.add(c.mul(b))
+    assert p.eval_at_point(x).tup() == want.tup()
+    with pytest.raises(ValueError, match="coeffs length must be power of two"):
+        T.LinePoly(co[:3])

@@ -414,7 +414,7 @@ def test_fri_commit_low_degree_and_transcript():
         cur = orc.fold_line(cur, k, coset_init, alpha.tup())
         coset_init = (coset_init * 2) & 0x7FFFFFFF
         k -= 1
-    ch2.mix_felts(prover.last_layer_poly)
+    ch2.mix_felts(prover.last_layer_poly.coeffs)
     assert ch.digest() == ch2.digest()
 
 
@@ -438,6 +438,134 @@ def test_fri_commit_two_columns_mixed_sizes():
     prover = T.FriProver.commit(T.Blake2sChannel(), cfg, [big, small], tw)
     assert len(prover.last_layer_poly) == 2
     assert len(prover.first_layer.merkle_tree.layers) == 11
+
+
+# ---------------------------------------------------------------- fri.test.ts: decommit + FriVerifier (Rust test_fri_* family)
+def _fri_prove(cols, tw, cfg):
+    ch = T.Blake2sChannel()
+    prover = T.FriProver.commit(ch, cfg, cols, tw)
+    proof, positions = prover.decommit(ch)
+    return prover, proof, positions
+
+
+def _query_evals(cols, positions):
+    return [c.values.gather(positions[c.domain.logSize()]) for c in cols]
+
+
+def _fri_verify(cfg, proof, bounds, query_evals, expect_positions=None):
+    ch = T.Blake2sChannel()
+    v = T.FriVerifier.commit(ch, cfg, proof, [T.CirclePolyDegreeBound(b) for b in bounds])
+    pos = v.sample_query_positions(ch)
+    if expect_positions is not None:
+        assert pos == expect_positions                   # verifier's transcript reproduces the prover's queries
+    v.decommit(query_evals)
+    return v
+
+
+def test_fri_prove_verify_single_column():
+    """Rust fri.rs valid_proof_passes_verification: commit + decommit on the GPU, verify on the host."""
+    cfg = T.FriConfig(2, 2, 12)
+    col, tw = _secure_low_degree_eval(8, 2, 6000)
+    _, proof, positions = _fri_prove([col], tw, cfg)
+    assert len(proof.inner_layers) == 9 - 4
+    _fri_verify(cfg, proof, [8], _query_evals([col], positions), positions)
+
+
+def test_fri_prove_verify_mixed_degree_columns():
+    """Rust fri.rs valid_mixed_degree_proof_passes_verification: columns of log degree 9, 7, 5 under one first-layer tree."""
+    cfg = T.FriConfig(1, 2, 10)
+    cols, tw = [], None
+    for i, lg in enumerate([9, 7, 5]):
+        c, t = _secure_low_degree_eval(lg, 2, 7000 + 10 * i)
+        cols.append(c)
+        tw = tw or t
+    _, proof, positions = _fri_prove(cols, tw, cfg)
+    assert sorted(positions) == [7, 9, 11]
+    _fri_verify(cfg, proof, [9, 7, 5], _query_evals(cols, positions), positions)
+
+
+def test_fri_verifier_rejects_tampering():
+    """Rust fri.rs proof_with_*_fails_verification cases, with the reference's FriVerificationError texts."""
+    import copy
+    cfg = T.FriConfig(2, 2, 8)
+    col, tw = _secure_low_degree_eval(8, 2, 8000)
+    _, proof, positions = _fri_prove([col], tw, cfg)
+    evals = _query_evals([col], positions)
+    # removed inner layer
+    bad = copy.deepcopy(proof)
+    bad.inner_layers.pop()
+    with pytest.raises(T.FriVerificationError, match="invalid number of FRI layers"):
+        _fri_verify(cfg, bad, [8], evals)
+    # added inner layer
+    bad = copy.deepcopy(proof)
+    bad.inner_layers.append(copy.deepcopy(bad.inner_layers[-1]))
+    with pytest.raises(T.FriVerificationError, match="invalid number of FRI layers"):
+        _fri_verify(cfg, bad, [8], evals)
+    # an evaluation of the first layer changed: the transcript is unchanged, the Merkle check of layer 0 fails
+    bad_evals = [list(evals[0])]
+    bad_evals[0][0] = bad_evals[0][0].add(T.QM31.one())
+    with pytest.raises(T.FriVerificationError, match="do not resolve to their commitment in the first layer"):
+        _fri_verify(cfg, proof, [8], bad_evals)
+    # inner-layer witness value changed
+    bad = copy.deepcopy(proof)
+    assert bad.inner_layers[1].fri_witness
+    bad.inner_layers[1].fri_witness[0] = bad.inner_layers[1].fri_witness[0].add(T.QM31.one())
+    with pytest.raises(T.FriVerificationError, match="do not resolve to their commitment in inner layer 1"):
+        _fri_verify(cfg, bad, [8], evals)
+    # inner-layer witness too short
+    bad = copy.deepcopy(proof)
+    bad.inner_layers[0].fri_witness.pop()
+    with pytest.raises(T.FriVerificationError, match="evaluations are invalid in inner layer 0"):
+        _fri_verify(cfg, bad, [8], evals)
+    # last layer polynomial of too high degree
+    bad = copy.deepcopy(proof)
+    bad.last_layer_poly = T.LinePoly(list(bad.last_layer_poly.coeffs) * 2)
+    with pytest.raises(T.FriVerificationError, match="degree of last layer is invalid"):
+        _fri_verify(cfg, bad, [8], evals)
+    # last layer polynomial changed (Rust proof_with_invalid_last_layer_fails_verification); changes the transcript too, so
+    # replay the prover's queries directly
+    bad = copy.deepcopy(proof)
+    bad.last_layer_poly = T.LinePoly([bad.last_layer_poly.coeffs[0].add(T.QM31.one())] + list(bad.last_layer_poly.coeffs[1:]))
+    ch = T.Blake2sChannel()
+    v = T.FriVerifier.commit(ch, cfg, bad, [T.CirclePolyDegreeBound(8)])
+    with pytest.raises(T.FriVerificationError, match="evaluations in the last layer are invalid"):
+        v.decommit_on_queries(T.Queries(positions[10], 10), evals)
+
+
+def test_fri_constant_last_layer_and_invalid_query_domain():
+    """fri.test.ts valid_proof_with_constant_last_layer_passes_verification (query [5], last layer bound 0) and
+    decommit_queries_on_invalid_domain_fails_verification."""
+    LOG_DEG, BLOW = 3, 2
+    col, tw = _secure_low_degree_eval(LOG_DEG, BLOW, 8500)
+    queries = T.Queries.from_positions([5], LOG_DEG + BLOW)
+    cfg = T.FriConfig(0, BLOW, len(queries))
+    prover = T.FriProver.commit(T.Blake2sChannel(), cfg, [col], tw)
+    assert len(prover.last_layer_poly) == 1
+    proof = prover.decommit_on_queries(queries)
+    v = T.FriVerifier.commit(T.Blake2sChannel(), cfg, proof, [T.CirclePolyDegreeBound(LOG_DEG)])
+    v.decommit_on_queries(queries, [col.values.gather(queries.positions)])
+    with pytest.raises(ValueError, match="Domain size mismatch"):
+        v.decommit_on_queries(T.Queries.from_positions([2], LOG_DEG + BLOW - 1), [col.values.gather([2])])
+
+
+def test_fri_prove_verify_log16():
+    """A larger instance (degree 2^14, blowup 2, 20 queries): 11 inner layers stay on the GPU, proof verifies."""
+    cfg = T.FriConfig(3, 2, 20)
+    col, tw = _secure_low_degree_eval(14, 2, 9000)
+    _, proof, positions = _fri_prove([col], tw, cfg)
+    _fri_verify(cfg, proof, [14], _query_evals([col], positions), positions)
+
+
+def test_queries_generate_and_fold():
+    """queries.test.ts: sorted unique positions below the domain size; fold halves and de-duplicates."""
+    ch = T.Blake2sChannel()
+    q = T.Queries.generate(ch, 31, 100)
+    assert len(q) == 100 and list(q.positions) == sorted(set(q.positions)) and max(q.positions) < (1 << 31)
+    q = T.Queries.generate(T.Blake2sChannel(), 6, 20)
+    f = q.fold(2)
+    assert f.log_domain_size == 4 and f.positions == sorted({p >> 2 for p in q.positions})
+    with pytest.raises(TypeError, match="sorted in ascending order"):
+        T.Queries([3, 1], 4)
 
 
 # ---------------------------------------------------------------- pcs/prover.ts (Rust comment): commitment tree over HipBackend

@@ -123,6 +123,21 @@ class SecureColumnByCoords:
         for c, x in zip(self.columns, as_q4(v)):
             c.set(i, x)
 
+    def gather(self, positions) -> list:
+        """[self.at(p) for p in positions] with one device gather (tstwo_gather_words) instead of 4 reads per element."""
+        positions = list(positions)
+        if not positions:
+            return []
+        n, k = self.len(), len(positions)
+        for p in positions:
+            if p < 0 or p >= n:
+                raise IndexError(f"Index {p} out of bounds for column of length {n}")
+        srcs = L.ptr_array([c.ptr for c in self.columns for _ in positions])
+        idx = (C.c_uint64 * (4 * k))(*(positions * 4))
+        out = np.empty(4 * k, dtype=np.uint32)
+        L.call("tstwo_gather_words", srcs, idx, 1, 4 * k, out.ctypes.data_as(L.u32p))
+        return [QM31.from_u32_unchecked(*(int(out[c * k + i]) for c in range(4))) for i in range(k)]
+
     def to_numpy(self): return [c.to_numpy() for c in self.columns]
     def to_vec(self): return [QM31.from_u32_unchecked(*map(int, t)) for t in zip(*self.to_numpy())]
     toCpu = to_vec

@@ -6,12 +6,17 @@ coordinate columns (device resident), the root is mixed into the channel, and th
 Layers never leave HBM between fold and commit; only 32-byte roots and the (tiny) last layer reach the host."""
 from __future__ import annotations
 
+from dataclasses import dataclass, field
+
 from .backend import SecureColumnByCoords
 from .circle import Coset, LineDomain, bit_reverse_index
+from .queries import Queries, get_query_positions_by_log_size
 from .fields import M31, QM31
 from .fri import CIRCLE_TO_LINE_FOLD_STEP, HipFriOps
 from .poly import LineEvaluation, SecureEvaluation, TwiddleTree
-from .vcs import MerkleProver
+from .vcs import MerkleDecommitment, MerkleProver
+
+FOLD_STEP = 1
 
 
 class FriConfig:
@@ -69,9 +74,128 @@ def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = 
     return [v.mulM31(len_inv) for v in vals]
 
 
-class FriLayer:
-    def __init__(self, evaluation, merkle_tree: MerkleProver):
+class LinePoly:
+    """LinePoly (poly/line.ts:127-236): coefficients of the x-basis in bit-reversed order, QM31, on the host."""
+
+    def __init__(self, coeffs):
+        coeffs = list(coeffs)
+        if not coeffs or len(coeffs) & (len(coeffs) - 1):
+            raise ValueError("coeffs length must be power of two")
+        self.coeffs = coeffs
+        self._log_size = len(coeffs).bit_length() - 1
+
+    new = staticmethod(lambda coeffs: LinePoly(coeffs))
+
+    def len(self): return 1 << self._log_size
+    __len__ = len
+
+    def eval_at_point(self, x: QM31) -> QM31:
+        """line.ts:145-153 + fold (poly/utils.ts:36-59): doublings [x, pi(x), pi^2(x), ...], pi(x) = 2x^2 - 1."""
+        doublings, cur = [], x
+        for _ in range(self._log_size):
+            doublings.append(cur)
+            cur = cur.square().double().sub(QM31.one())
+
+        def fold(values, factors):
+            if len(values) == 1:
+                return values[0]
+            h = len(values) // 2
+            return fold(values[:h], factors[1:]).add(fold(values[h:], factors[1:]).mul(factors[0]))
+        return fold(self.coeffs, doublings)
+
+    evalAtPoint = eval_at_point
+
+    def into_ordered_coefficients(self) -> list:
+        return [self.coeffs[bit_reverse_index(i, self._log_size)] for i in range(len(self.coeffs))]
+
+    @staticmethod
+    def from_ordered_coefficients(coeffs) -> "LinePoly":
+        coeffs = list(coeffs)
+        lg = len(coeffs).bit_length() - 1
+        return LinePoly([coeffs[bit_reverse_index(i, lg)] for i in range(len(coeffs))])
+
+    intoOrderedCoefficients, fromOrderedCoefficients = into_ordered_coefficients, from_ordered_coefficients
+
+
+@dataclass
+class FriLayerProof:
+    """fri.ts:262-269."""
+    fri_witness: list = field(default_factory=list)          # QM31 the verifier cannot deduce
+    decommitment: MerkleDecommitment = field(default_factory=MerkleDecommitment)
+    commitment: bytes = b""
+
+
+@dataclass
+class FriProof:
+    """fri.ts:274-278."""
+    first_layer: FriLayerProof
+    inner_layers: list
+    last_layer_poly: LinePoly
+
+
+def compute_decommitment_positions_and_witness_evals(column: SecureColumnByCoords, query_positions, fold_step: int):
+    """fri.ts:346-384.  Same walk; the witness values are fetched from the device column with ONE gather."""
+    decommitment_positions, witness_positions = [], []
+    qs = list(query_positions)
+    i = 0
+    while i < len(qs):
+        coset = qs[i] >> fold_step
+        start = coset << fold_step
+        subset = []
+        while i < len(qs) and (qs[i] >> fold_step) == coset:
+            subset.append(qs[i])
+            i += 1
+        k = 0
+        for position in range(start, start + (1 << fold_step)):
+            decommitment_positions.append(position)
+            if k < len(subset) and subset[k] == position:            # the verifier can calculate this one
+                k += 1
+                continue
+            witness_positions.append(position)
+    return decommitment_positions, column.gather(witness_positions)
+
+
+computeDecommitmentPositionsAndWitnessEvals = compute_decommitment_positions_and_witness_evals
+
+
+class FriFirstLayerProver:
+    """Rust FriFirstLayerProver (TS mock at fri.ts:485-517): all circle columns under one Merkle tree."""
+
+    def __init__(self, columns, merkle_tree: MerkleProver):
+        self.columns, self.merkle_tree = list(columns), merkle_tree
+        self.evaluation = self.columns                                   # FriLayer-compatible view
+
+    def column_log_sizes(self): return {c.domain.logSize() for c in self.columns}
+    def max_column_log_size(self): return max(self.column_log_sizes())
+    columnLogSizes, maxColumnLogSize = column_log_sizes, max_column_log_size
+
+    def decommit(self, queries: Queries) -> FriLayerProof:
+        max_log = queries.log_domain_size
+        assert max_log == self.max_column_log_size()
+        fri_witness, positions_by_log = [], {}
+        for column in self.columns:
+            lg = column.domain.logSize()
+            cq = queries.fold(max_log - lg)
+            pos, wit = compute_decommitment_positions_and_witness_evals(column.values, cq.positions, CIRCLE_TO_LINE_FOLD_STEP)
+            positions_by_log[lg] = pos
+            fri_witness += wit
+        _, dec = self.merkle_tree.decommit(positions_by_log, [cc for c in self.columns for cc in c.values.columns])
+        return FriLayerProof(fri_witness, dec, self.merkle_tree.root())
+
+
+class FriInnerLayerProver:
+    """Rust FriInnerLayerProver (TS mock at fri.ts:519-542): one line evaluation, its 4 coordinate columns committed."""
+
+    def __init__(self, evaluation: LineEvaluation, merkle_tree: MerkleProver):
         self.evaluation, self.merkle_tree = evaluation, merkle_tree
+
+    def decommit(self, queries: Queries) -> FriLayerProof:
+        pos, wit = compute_decommitment_positions_and_witness_evals(self.evaluation.values, queries.positions, FOLD_STEP)
+        _, dec = self.merkle_tree.decommit({self.evaluation.domain().logSize(): pos}, self.evaluation.values.columns)
+        return FriLayerProof(wit, dec, self.merkle_tree.root())
+
+
+FriLayer = FriInnerLayerProver
 
 
 class FriProver:
@@ -92,7 +216,7 @@ class FriProver:
         coord_cols = [cc for c in columns for cc in c.values.columns]
         first_tree = MerkleProver.commit(coord_cols)
         channel.mix_root(first_tree.root())
-        first_layer = FriLayer(columns, first_tree)
+        first_layer = FriFirstLayerProver(columns, first_tree)
 
         folded = lambda v: v.domain.size() >> CIRCLE_TO_LINE_FOLD_STEP
         first_log = (folded(columns[0])).bit_length() - 1
@@ -106,12 +230,14 @@ class FriProver:
             tree = MerkleProver.commit(layer_eval.values.columns)           # FriInnerLayerProver::new
             channel.mix_root(tree.root())
             alpha = channel.draw_felt()
-            layer = FriLayer(layer_eval, tree)
+            layer = FriInnerLayerProver(layer_eval, tree)
             layer_eval = HipFriOps.fold_line(layer_eval, alpha, twiddles)
             if nxt is not None and folded(nxt) == layer_eval.len():
                 HipFriOps.fold_circle_into_line(layer_eval, nxt, alpha, twiddles)
                 nxt = next(it, None)
             inner.append(layer)
+        if nxt is not None:
+            raise ValueError("not all columns were consumed")                # Rust: assert!(columns.is_empty())
         # last layer (fri.ts:718-754)
         if layer_eval.len() != config.last_layer_domain_size():
             raise ValueError("last layer domain size mismatch")
@@ -121,6 +247,25 @@ class FriProver:
         bound = 1 << config.log_last_layer_degree_bound
         if any(c.tup() != (0, 0, 0, 0) for c in ordered[bound:]):
             raise ValueError("invalid degree")
-        last = ordered[:bound]
-        channel.mix_felts(last)
+        last = LinePoly.from_ordered_coefficients(ordered[:bound])
+        channel.mix_felts(last.coeffs)          # Rust: channel.mix_felts(&last_layer_poly) = its bit-reversed coefficient slice
         return FriProver(config, first_layer, inner, last)
+
+    def decommit(self, channel) -> tuple:
+        """fri.ts:759-766: draws the queries, returns (FriProof, query positions by column log size)."""
+        max_log = self.first_layer.max_column_log_size()
+        queries = Queries.generate(channel, max_log, self.config.n_queries)
+        by_log = get_query_positions_by_log_size(queries, self.first_layer.column_log_sizes())
+        return self.decommit_on_queries(queries), by_log
+
+    def decommit_on_queries(self, queries: Queries) -> FriProof:
+        """fri.ts:768-785."""
+        first = self.first_layer.decommit(queries)
+        inner = []
+        layer_queries = queries.fold(CIRCLE_TO_LINE_FOLD_STEP)
+        for layer in self.inner_layers:
+            inner.append(layer.decommit(layer_queries))
+            layer_queries = layer_queries.fold(FOLD_STEP)
+        return FriProof(first, inner, self.last_layer_poly)
+
+    decommitOnQueries = decommit_on_queries
