@@ -607,6 +607,110 @@ def test_commitment_scheme_prover_roundtrip():
     T.MerkleVerifier(T.Blake2sMerkleHasher(), oroot, [LOG + BLOW] * 5 + [LOG - 2 + BLOW] * 2).verify(queries, values, dec)
 
 
+def _pcs_setup(config, col_logs_per_tree, seed=11000):
+    """Commit trees of random trace columns (evaluations on canonic trace domains) the way a stwo prover does."""
+    blow = config.fri_config.log_blowup_factor
+    max_log = max(lg for t in col_logs_per_tree for lg in t)
+    tw = T.precompute_twiddles(T.CanonicCoset(max_log + blow).circleDomain().halfCoset)
+    scheme = T.CommitmentSchemeProver(config, tw)
+    ch = T.Blake2sChannel()
+    config.mix_into(ch)
+    for ti, logs in enumerate(col_logs_per_tree):
+        tb = scheme.tree_builder()
+        tb.extend_evals([T.HipCircleEvaluation(T.CanonicCoset(lg).circleDomain(), rand_column(seed + 100 * ti + c, 1 << lg))
+                         for c, lg in enumerate(logs)])
+        tb.commit(ch)
+    return scheme, ch
+
+
+def _pcs_verifier(config, col_logs_per_tree, roots):
+    v = T.CommitmentSchemeVerifier(config)
+    ch = T.Blake2sChannel()
+    config.mix_into(ch)
+    for logs, root in zip(col_logs_per_tree, roots):
+        v.commit(root, logs, ch)
+    return v, ch
+
+
+def test_pcs_prove_values_and_verify():
+    """pcs/prover.ts + pcs/verifier.ts (Rust text): commit two trees of mixed sizes, open every column at an out-of-domain
+    point drawn from the channel (one column at two points), prove on the GPU, verify on the host."""
+    config = T.PcsConfig(pow_bits=10, fri_config=T.FriConfig(2, 2, 8))
+    logs = [[10, 10, 8], [10, 9]]
+    scheme, ch = _pcs_setup(config, logs)
+    point = T.CirclePoint.get_random_point(ch)
+    shifted = point.add(T.SECURE_FIELD_CIRCLE_GEN)
+    sampled_points = [[[point], [point, shifted], [point]], [[point], [point]]]
+    proof = scheme.prove_values(sampled_points, ch)
+    assert proof.commitments == scheme.roots() and len(proof.sampled_values[0][1]) == 2
+    # sampled values are the polynomials' values at the point (eval_at_point parity is covered by the C-ABI tests)
+    verifier, vch = _pcs_verifier(config, logs, proof.commitments)
+    vpoint = T.CirclePoint.get_random_point(vch)
+    assert vpoint.x.tup() == point.x.tup()
+    vshift = vpoint.add(T.SECURE_FIELD_CIRCLE_GEN)
+    verifier.verify_values([[[vpoint], [vpoint, vshift], [vpoint]], [[vpoint], [vpoint]]], proof, vch)
+    assert ch.digest() == vch.digest()                       # both transcripts end in the same state
+
+
+def test_pcs_verify_rejects_bad_proofs():
+    import copy
+    config = T.PcsConfig(pow_bits=6, fri_config=T.FriConfig(1, 1, 6))
+    logs = [[7, 6]]
+    scheme, ch = _pcs_setup(config, logs, seed=12000)
+    point = T.CirclePoint.get_random_point(ch)
+    pts = [[[point], [point]]]
+    proof = scheme.prove_values(pts, ch)
+
+    def verify(pr, cfg=config):
+        v, vch = _pcs_verifier(cfg, logs, pr.commitments)
+        T.CirclePoint.get_random_point(vch)
+        v.verify_values(pts, pr, vch)
+    verify(proof)
+    # a queried trace value changed -> the tree's Merkle decommitment fails
+    bad = copy.deepcopy(proof)
+    bad.queried_values[0][0] = bad.queried_values[0][0].add(T.M31.one())
+    with pytest.raises(T.VerificationError, match="Merkle verification failed"):
+        verify(bad)
+    # a sampled value changed -> different transcript; the proof cannot verify
+    bad = copy.deepcopy(proof)
+    bad.sampled_values[0][0][0] = bad.sampled_values[0][0][0].add(T.QM31.one())
+    with pytest.raises((T.VerificationError, T.FriVerificationError)):
+        verify(bad)
+    # wrong nonce -> proof of work (or, with probability 2^-6, a later failure)
+    bad = copy.deepcopy(proof)
+    bad.proof_of_work += 1
+    with pytest.raises((T.VerificationError, T.FriVerificationError)):
+        verify(bad)
+    # claiming a sampled value the polynomial does not take: the prover itself cannot produce a low-degree quotient
+    scheme2, ch2 = _pcs_setup(config, logs, seed=12000)
+    p2 = T.CirclePoint.get_random_point(ch2)
+    orig = T.HipCirclePoly.eval_at_point
+    try:
+        T.HipCirclePoly.eval_at_point = staticmethod(lambda poly, pt: orig(poly, pt).add(T.QM31.one()))
+        with pytest.raises(ValueError, match="invalid degree"):
+            scheme2.prove_values([[[p2], [p2]]], ch2)
+    finally:
+        T.HipCirclePoly.eval_at_point = staticmethod(orig)
+
+
+def test_fri_answers_match_device_quotients():
+    """fri_answers (host row quotients at the queries) == the device accumulate_quotients column gathered at the queries."""
+    LOG, BLOW = 8, 1
+    tw = T.precompute_twiddles(T.CanonicCoset(LOG + BLOW).circleDomain().halfCoset)
+    polys = [T.HipCirclePoly(rand_column(13000 + c, 1 << LOG)) for c in range(3)]
+    domain = T.CanonicCoset(LOG + BLOW).circleDomain()
+    evals = T.evaluate_polynomials(polys, domain, tw)
+    pt = T.SECURE_FIELD_CIRCLE_GEN
+    samples = [[T.PointSample(pt, p.evalAtPoint(pt))] for p in polys]
+    coeff = T.QM31.from_u32_unchecked(1, 2, 3, 4)
+    quot = T.compute_fri_quotients(evals, samples, coeff, BLOW)[0]
+    queries = [0, 5, 100, 511]
+    got = quot.values.gather(queries)
+    vals = [int(e.values.to_numpy()[q]) for q in queries for e in evals]
+    ans = T.fri_answers([[LOG + BLOW] * 3], [samples], coeff, {LOG + BLOW: queries}, [[T.M31(v) for v in vals]], [{LOG + BLOW: 3}])
+    assert [a.tup() for a in ans[0]] == [g.tup() for g in got]
+
+
 # ---------------------------------------------------------------- proof_of_work / backend/cpu/grind.ts
 @pytest.mark.parametrize("pow_bits", [0, 1, 8, 14, 20])
 def test_grind_matches_sequential_reference_loop(pow_bits):

@@ -16,7 +16,10 @@ from .fri_verifier import (CirclePolyDegreeBound, FriVerificationError, FriVerif
                            SparseEvaluation, accumulate_line, compute_decommitment_positions_and_rebuild_evals)
 from .queries import Queries, get_query_positions_by_log_size  # noqa: F401
 from .fri import HipFriOps, decompose, fold_circle_into_line, fold_line  # noqa: F401
-from .pcs import CommitmentSchemeProver, CommitmentTreeProver, TreeBuilder  # noqa: F401
+from .pcs import (CommitmentSchemeProof, CommitmentSchemeProver, CommitmentTreeProver, PcsConfig, PointSample,  # noqa: F401
+                  TreeBuilder, column_sample_batches, compute_fri_quotients)
+from .pcs_verifier import (CommitmentSchemeVerifier, VerificationError, accumulate_row_quotients,  # noqa: F401
+                           fri_answers)
 from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureEvaluation, TwiddleTree,  # noqa: F401
                    evaluate_polynomials, interpolate_columns, precompute_twiddles)
 from .quotients import (ColumnSampleBatch, accumulate, accumulateQuotients, generate_secure_powers,  # noqa: F401

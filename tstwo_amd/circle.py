@@ -38,6 +38,14 @@ class CirclePoint:
         return res
 
     def equals(self, o): return self.x == o.x and self.y == o.y
+
+    @staticmethod
+    def get_random_point(channel) -> "CirclePoint":
+        """circle.ts:126-133: a secure-field circle point from one drawn felt t: ((1-t^2)/(1+t^2), 2t/(1+t^2))."""
+        t = channel.draw_felt()
+        t2 = t.square()
+        inv = t2.add(QM31.one()).inverse()
+        return CirclePoint(QM31.one().sub(t2).mul(inv), t.double().mul(inv))
     __eq__ = equals
     def __repr__(self): return f"CirclePoint({self.x}, {self.y})"
 

@@ -6,9 +6,76 @@ evaluate_polynomials(log_blowup_factor) -> MerkleProver.commit -> MC::mix_root. 
 the 32-byte root stays in HBM."""
 from __future__ import annotations
 
-from .circle import CanonicCoset
+from dataclasses import dataclass, field
+
+from .channel import grind
+from .circle import CanonicCoset, CirclePoint
+from .fields import QM31
+from .fri_prover import FriConfig, FriProof, FriProver
 from .poly import HipCirclePoly, TwiddleTree, evaluate_polynomials, interpolate_columns
+from .quotients import ColumnSampleBatch, accumulateQuotients
 from .vcs import MerkleProver
+
+
+@dataclass
+class PcsConfig:
+    """pcs/index.ts (Rust mod.rs text): proof-of-work bits + FRI parameters; Default = (5, FriConfig(0, 1, 3))."""
+    pow_bits: int = 5
+    fri_config: FriConfig = field(default_factory=lambda: FriConfig(0, 1, 3))
+
+    def security_bits(self) -> int:
+        return self.pow_bits + self.fri_config.security_bits()
+
+    def mix_into(self, channel) -> None:
+        channel.mix_u64(self.pow_bits)
+        self.fri_config.mixInto(channel)
+
+
+@dataclass
+class PointSample:
+    """pcs/quotients.ts (Rust text :77-80)."""
+    point: CirclePoint
+    value: QM31
+
+
+def column_sample_batches(samples) -> list:
+    """ColumnSampleBatch::new_vec (pcs/quotients.ts Rust text :48-75): group the per-column samples by point, keeping
+    first-seen order (IndexMap)."""
+    grouped = {}
+    for column_index, col_samples in enumerate(samples):
+        for s in col_samples:
+            key = (s.point.x.tup(), s.point.y.tup())
+            grouped.setdefault(key, (s.point, []))[1].append((column_index, s.value))
+    return [ColumnSampleBatch(point, cv) for point, cv in grouped.values()]
+
+
+def compute_fri_quotients(columns, samples, random_coeff: QM31, log_blowup_factor: int) -> list:
+    """compute_fri_quotients (pcs/quotients.ts Rust text :82-109): columns grouped by log size (descending, stable), one
+    accumulate_quotients launch per size on the canonic domain of that size."""
+    order = sorted(range(len(columns)), key=lambda i: -columns[i].domain.logSize())
+    out, i = [], 0
+    while i < len(order):
+        log_size = columns[order[i]].domain.logSize()
+        grp = []
+        while i < len(order) and columns[order[i]].domain.logSize() == log_size:
+            grp.append(order[i])
+            i += 1
+        domain = CanonicCoset(log_size).circleDomain()
+        batches = column_sample_batches([samples[j] for j in grp])
+        out.append(accumulateQuotients(domain, [columns[j] for j in grp], random_coeff, batches, log_blowup_factor))
+    return out
+
+
+@dataclass
+class CommitmentSchemeProof:
+    """pcs/prover.ts Rust text :158-167.  TreeVec = list indexed by tree; ColumnVec = list indexed by column."""
+    config: PcsConfig
+    commitments: list
+    sampled_values: list
+    decommitments: list
+    queried_values: list
+    proof_of_work: int
+    fri_proof: FriProof
 
 
 class CommitmentTreeProver:
@@ -61,8 +128,12 @@ class TreeBuilder:
 class CommitmentSchemeProver:
     """pcs/prover.ts:26-80 (Rust comment): a list of commitment trees sharing one twiddle tree."""
 
-    def __init__(self, log_blowup_factor: int, twiddles: TwiddleTree):
-        self.log_blowup_factor, self.twiddles, self.trees = log_blowup_factor, twiddles, []
+    def __init__(self, config, twiddles: TwiddleTree):
+        """config: a PcsConfig (as in Rust) or, for commitment-only use, just the log blowup factor."""
+        if isinstance(config, int):
+            config = PcsConfig(fri_config=FriConfig(0, config, 3))
+        self.config, self.twiddles, self.trees = config, twiddles, []
+        self.log_blowup_factor = config.fri_config.log_blowup_factor
 
     def tree_builder(self) -> TreeBuilder:
         return TreeBuilder(self)
@@ -72,3 +143,33 @@ class CommitmentSchemeProver:
 
     def roots(self) -> list:
         return [t.commitment.root() for t in self.trees]
+
+    def polynomials(self) -> list:
+        return [list(t.polynomials) for t in self.trees]
+
+    def evaluations(self) -> list:
+        return [list(t.evaluations) for t in self.trees]
+
+    def prove_values(self, sampled_points, channel) -> CommitmentSchemeProof:
+        """prove_values (pcs/prover.ts Rust text :82-155).  sampled_points[tree][column] = list of CirclePoint<QM31>.
+        Out-of-domain evaluation, quotients, FRI commit, grinding and every decommitment read device-resident data;
+        only sampled values, roots, witnesses and queried values reach the host."""
+        # "Evaluate columns out of domain"
+        samples = [[[PointSample(pt, poly.evalAtPoint(pt)) for pt in pts] for poly, pts in zip(tree.polynomials, tree_pts)]
+                   for tree, tree_pts in zip(self.trees, sampled_points)]
+        sampled_values = [[[s.value for s in col] for col in tree] for tree in samples]
+        channel.mix_felts([v for tree in sampled_values for col in tree for v in col])
+        # OODS quotients over every tree's evaluations, flattened
+        columns = [ev for t in self.trees for ev in t.evaluations]
+        flat_samples = [col for tree in samples for col in tree]
+        quotients = compute_fri_quotients(columns, flat_samples, channel.draw_felt(), self.log_blowup_factor)
+        # FRI commitment phase on the quotients
+        fri_prover = FriProver.commit(channel, self.config.fri_config, quotients, self.twiddles)
+        # proof of work
+        proof_of_work = grind(channel, self.config.pow_bits)
+        channel.mix_u64(proof_of_work)
+        # FRI decommitment phase, then the trace trees on the same queries
+        fri_proof, query_positions = fri_prover.decommit(channel)
+        results = [t.decommit(query_positions) for t in self.trees]
+        return CommitmentSchemeProof(self.config, self.roots(), sampled_values, [d for _, d in results],
+                                     [v for v, _ in results], proof_of_work, fri_proof)
