@@ -120,6 +120,16 @@ int tstwo_fri_fold_line(const uint32_t *const in[4], uint32_t log_n, const uint3
  * dst_len != 2^(log_n-1) -> TSTWO_ERR_LEN_MISMATCH. */
 int tstwo_fri_fold_circle_into_line(uint32_t *const dst[4], size_t dst_len, const uint32_t *const src[4],
                                     uint32_t log_n, const uint32_t *itw, uint32_t tw_log, const uint32_t alpha[4]);
+/* Row shards of a FRI layer for multi-GPU provers (SURVEY.md 8e "contiguous row sharding"; output i of fri.ts:120-192
+ * depends on inputs 2i, 2i+1 only).  `in`/`src` hold input rows [2*row_offset, 2*(row_offset+n_rows)) and `out`/`dst`
+ * output rows [row_offset, row_offset+n_rows) of a layer of 2^log_n input rows.  row_offset and n_rows are multiples
+ * of 4 (TSTWO_ERR_BAD_ARG otherwise).  The concatenation over shards equals tstwo_fri_fold_line /
+ * tstwo_fri_fold_circle_into_line on the whole layer. */
+int tstwo_fri_fold_line_rows(const uint32_t *const in[4], uint32_t log_n, size_t row_offset, size_t n_rows,
+                             const uint32_t *itw, uint32_t tw_log, const uint32_t alpha[4], uint32_t *const out[4]);
+int tstwo_fri_fold_circle_into_line_rows(uint32_t *const dst[4], const uint32_t *const src[4], uint32_t log_n,
+                                         size_t row_offset, size_t n_rows, const uint32_t *itw, uint32_t tw_log,
+                                         const uint32_t alpha[4]);
 /* Variants taking the n/2 per-output inverse twiddles explicitly (domains that are not a doubling
  * of a precomputed tree, and log_n < 3 for the circle fold). */
 int tstwo_fri_fold_line_tw(const uint32_t *const in[4], uint32_t log_n, const uint32_t *inv_x,

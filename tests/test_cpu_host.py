@@ -163,6 +163,62 @@ def test_allgather_roots_world2_gloo(tmp_path):
         assert f"rank {r} ok" in o
 
 
+_WORKER_ROWS = r"""
+import hashlib, os, sys
+sys.path.insert(0, os.environ["TSTWO_ROOT"])
+import numpy as np
+import torch.distributed as dist
+from tstwo_amd.distributed import commit_rows_sharded, shard_rows
+from oracle import oracle as orc     # test infrastructure: stands in for the GPU commit on this GPU-less box
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+LOG = 7
+cols = [np.random.default_rng(200 + c).integers(0, 2**31 - 1, size=1 << LOG, dtype=np.uint32) for c in range(4)]
+small = np.random.default_rng(300).integers(0, 2**31 - 1, size=1 << (LOG - 2), dtype=np.uint32)
+class Tree:
+    def __init__(self, cs): self.r = orc.merkle_commit(cs, [int(c.size).bit_length() - 1 for c in cs])[1]
+    def root(self): return self.r
+def rows(c):
+    s, n = shard_rows(c.size, world, rank)
+    return c[s:s + n]
+tree, subroots, root = commit_rows_sharded([rows(c) for c in cols] + [rows(small)], Tree)
+_, expect = orc.merkle_commit(cols + [small], [LOG] * 4 + [LOG - 2])
+assert root == expect, (rank, root.hex(), expect.hex())
+assert subroots[rank] == tree.root() and len(subroots) == world
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_row_sharded_merkle_world2_gloo(tmp_path):
+    """SURVEY 8(e) row sharding on CPU: 2 ranks hash contiguous leaf ranges of a mixed-size tree to subtree roots,
+    all-gather them (gloo) and compute the top level redundantly; the result equals the single-tree root."""
+    script = tmp_path / "worker_rows.py"
+    script.write_text(_WORKER_ROWS)
+    env = dict(os.environ, TSTWO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_combine_subtree_roots_and_shard_rows():
+    import hashlib
+    from tstwo_amd.distributed import combine_subtree_roots, shard_rows
+    r = [bytes([i]) * 32 for i in range(4)]
+    h = lambda a, b: hashlib.blake2s(a + b).digest()
+    assert combine_subtree_roots(r) == h(h(r[0], r[1]), h(r[2], r[3]))
+    assert combine_subtree_roots(r[:1]) == r[0]
+    assert shard_rows(64, 4, 3) == (48, 16)
+    with pytest.raises(ValueError):
+        shard_rows(8, 4, 0)          # shards of 2 rows: below the 4-row alignment of the fold kernels
+    with pytest.raises(ValueError):
+        combine_subtree_roots(r[:3])
+
+
 def test_allgather_roots_single_process():
     from tstwo_amd.distributed import allgather_roots
     assert allgather_roots(b"\x01" * 32) == [b"\x01" * 32]

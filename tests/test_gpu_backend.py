@@ -1,6 +1,8 @@
 """-m gpu tests of the host-side mirror (HipBackend & friends), written to read like the reference's own tests:
 packages/core/test/backend/backend.test.ts, test/backend/cpu/circle.test.ts, test/poly/circleEvaluation.test.ts,
 test/fri.test.ts, test/backend/cpu/fri.test.ts, test/vcs/prover.test.ts, test/backend/cpu/quotients.test.ts."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -742,3 +744,48 @@ def test_line_interpolate_with_and_without_tree():
     a = T.line_interpolate(ev, tw)
     b = T.line_interpolate(ev, None)
     assert [x.tup() for x in a] == [x.tup() for x in b]
+
+
+# ---------------------------------------------------------------- row sharding of FRI layers / one big tree
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_row_sharded_fold_and_commit_match_single_gpu(world):
+    """Virtual ranks in one process: every rank folds and commits only its contiguous rows; concatenated folds and the
+    combined subtree roots equal the whole-layer results (the exchange itself is covered by the gloo test)."""
+    from tstwo_amd import distributed as D
+    n = 12
+    domain = T.CanonicCoset(n).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    src_np = [rand_column(15000 + k, 1 << n) for k in range(4)]
+    dst_np = [rand_column(15100 + k, 1 << (n - 1)) for k in range(4)]
+    alpha = T.QM31.from_u32_unchecked(19283, 1, 2, 3)
+    src = T.SecureEvaluation(domain, T.SecureColumnByCoords.from_numpy(src_np))
+    dst = T.LineEvaluation(T.LineDomain(domain.halfCoset), T.SecureColumnByCoords.from_numpy(dst_np))
+    T.fold_circle_into_line(dst, src, alpha, tw)
+    line = T.fold_line(dst, alpha, tw)
+    whole_circle, whole_line = dst.values.to_numpy(), line.values.to_numpy()
+    whole_root = T.MerkleProver.commit(dst.values.columns).root()
+    got_circle, got_line, subroots = [], [], []
+    for rank in range(world):
+        s, c = D.shard_rows(1 << (n - 1), world, rank)
+        d = T.SecureColumnByCoords.from_numpy([x[s:s + c] for x in dst_np])
+        D.fold_circle_into_line_rows(d, T.SecureColumnByCoords.from_numpy([x[2 * s:2 * (s + c)] for x in src_np]), n, rank, world, alpha, tw)
+        got_circle.append(d.to_numpy())
+        subroots.append(T.MerkleProver.commit(d.columns).root())
+        # next layer: this rank's rows of the line layer (2^(n-1) rows) fold to its rows of the layer below
+        s2, c2 = D.shard_rows(1 << (n - 2), world, rank)
+        shard = T.SecureColumnByCoords.from_numpy([x[2 * s2:2 * (s2 + c2)] for x in whole_circle])
+        got_line.append(D.fold_line_rows(shard, n - 1, rank, world, alpha, tw).to_numpy())
+    for k in range(4):
+        assert (np.concatenate([g[k] for g in got_circle]) == whole_circle[k]).all()
+        assert (np.concatenate([g[k] for g in got_line]) == whole_line[k]).all()
+    assert D.combine_subtree_roots(subroots) == whole_root
+
+
+def test_row_shard_rejects_misaligned():
+    from tstwo_amd import distributed as D
+    n = 6
+    tw = T.precompute_twiddles(T.CanonicCoset(n).circleDomain().halfCoset)
+    sh = T.SecureColumnByCoords.zeros(12)
+    with pytest.raises(L.TstwoError, match="4-aligned"):
+        L.call("tstwo_fri_fold_line_rows", sh.ptrs(), n - 1, 2, 6, C.c_void_p(tw.itwiddles.ptr), tw.log_size,
+               L.u32x([1, 0, 0, 0]), T.SecureColumnByCoords.zeros(6).ptrs())

@@ -184,6 +184,51 @@ int tstwo_fri_fold_circle_into_line(u32 *const dst[4], size_t dst_len, const u32
     return fold_circle_common(true, dst, dst_len, src, log_n, seg1, alpha);
 }
 
+// ---- row shards (contiguous row sharding of FRI layers, no exchange): the pointers address this
+// shard's rows only; log_n is the WHOLE layer's size; the shard produces output rows [row_offset, row_offset+n_rows).
+static int check_shard(const char *fn, u32 log_n, size_t row_offset, size_t n_rows) {
+    size_t n_out = (size_t)1 << (log_n - 1);
+    if (n_rows == 0 || row_offset + n_rows > n_out || (row_offset & 3) || ((n_rows & 3) && n_rows != n_out)) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "%s: shard rows [%zu, +%zu) must be 4-aligned and lie inside the %zu output rows", fn, row_offset, n_rows, n_out);
+        return set_error(TSTWO_ERR_BAD_ARG, buf);
+    }
+    return TSTWO_OK;
+}
+
+int tstwo_fri_fold_line_rows(const u32 *const in[4], u32 log_n, size_t row_offset, size_t n_rows, const u32 *itw, u32 tw_log,
+                             const u32 alpha[4], u32 *const out[4]) {
+    TSTWO_REQUIRE_READY();
+    if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
+    if (tw_log > 31 || log_n > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    int rc = check_shard("fold_line_rows", log_n, row_offset, n_rows);
+    if (rc) return rc;
+    const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << log_n) + row_offset;
+    CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, i4, o4, n_rows, seg, to_q(alpha));
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_fri_fold_circle_into_line_rows(u32 *const dst[4], const u32 *const src[4], u32 log_n, size_t row_offset, size_t n_rows,
+                                         const u32 *itw, u32 tw_log, const u32 alpha[4]) {
+    TSTWO_REQUIRE_READY();
+    if (log_n < 3 || log_n > 31) return set_error(TSTWO_ERR_BAD_ARG, "fold_circle_into_line_rows: log_n must be in [3, 31]");
+    if (tw_log > 31 || log_n - 1 > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    int rc = check_shard("fold_circle_into_line_rows", log_n, row_offset, n_rows);
+    if (rc) return rc;
+    // the kernel reads seg1[(i>>1)^1] with sign (i ^ (i>>1)) & 1: both are invariant under a 4-aligned shift of i
+    const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (log_n - 1)) + (row_offset >> 1);
+    host::Q a = to_hq(alpha);
+    host::Q a2 = host::qmul(a, a);
+    Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
+    CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
+    hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, d4, s4, n_rows, seg1, to_q(a), to_q(a2));
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
 int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32 lambda[4]) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return set_error(TSTWO_ERR_BAD_ARG, "decompose: empty evaluation");

@@ -32,3 +32,63 @@ def commit_sharded(columns, rank: int, world: int, commit_fn, group=None):
     mine = [columns[i] for i in shard_columns(len(columns), world, rank)]
     tree = commit_fn(mine)
     return tree, allgather_roots(tree.root(), group=group)
+
+
+# ---------------------------------------------------------------- row sharding of one big tree / FRI layer
+def shard_rows(n_rows: int, world: int, rank: int) -> tuple:
+    """Contiguous row shard [start, start + count) of a power-of-two layer; world must be a power of two <= n_rows / 4."""
+    if world & (world - 1) or n_rows % world or (n_rows // world) % 4:
+        raise ValueError("row sharding needs a power-of-two world size and shards of a multiple of 4 rows")
+    per = n_rows // world
+    return rank * per, per
+
+
+def combine_subtree_roots(roots) -> bytes:
+    """Top log2(world) levels of a row-sharded Merkle tree: rank r's tree over its contiguous leaf range is the
+    subtree rooted at node r of level log2(world); the levels above hold no column values, so each node is
+    H(left || right) (hashNode, vcs/blake2_merkle.ts:9-24).  Computed redundantly on every rank (world - 1 hashes)."""
+    import hashlib
+    level = list(roots)
+    if len(level) & (len(level) - 1):
+        raise ValueError("number of subtree roots must be a power of two")
+    while len(level) > 1:
+        level = [hashlib.blake2s(level[2 * i] + level[2 * i + 1]).digest() for i in range(len(level) // 2)]
+    return level[0]
+
+
+def commit_rows_sharded(shard_columns_, commit_fn, group=None):
+    """Commit this rank's ROW shard of every column (each shard a power-of-two number of rows) and combine:
+    returns (local_subtree, [subtree_root_0..], root) with root bit-identical to the single-GPU MerkleProver.commit
+    over the whole columns.  The only exchange is the all-gather of world x 32 bytes."""
+    tree = commit_fn(shard_columns_)
+    roots = allgather_roots(tree.root(), group=group)
+    return tree, roots, combine_subtree_roots(roots)
+
+
+def fold_line_rows(shard, log_n: int, rank: int, world: int, alpha, twiddles):
+    """fold_line (fri.ts:120-152) of this rank's row shard of a line layer of 2^log_n rows on a domain that is a
+    doubling of the tree's root: `shard` holds input rows [2*start, 2*(start+count)); returns output rows
+    [start, start+count) as a SecureColumnByCoords.  No exchange: output i needs inputs 2i, 2i+1 only."""
+    from . import _lib as L
+    from .backend import SecureColumnByCoords, _vp
+    from .fields import as_q4
+    start, count = shard_rows(1 << (log_n - 1), world, rank)
+    if shard.len() != 2 * count:
+        raise ValueError("shard length does not match its row range")
+    out = SecureColumnByCoords.uninitialized(count)
+    L.call("tstwo_fri_fold_line_rows", shard.ptrs(), log_n, start, count, _vp(twiddles.itwiddles.ptr), twiddles.log_size,
+           L.u32x(as_q4(alpha)), out.ptrs())
+    return out
+
+
+def fold_circle_into_line_rows(dst_shard, src_shard, log_n: int, rank: int, world: int, alpha, twiddles) -> None:
+    """fold_circle_into_line (fri.ts:162-192) on row shards: src_shard = rows [2*start, 2*(start+count)) of a circle
+    evaluation of 2^log_n rows, dst_shard = rows [start, start+count) of the line layer, updated in place."""
+    from . import _lib as L
+    from .backend import _vp
+    from .fields import as_q4
+    start, count = shard_rows(1 << (log_n - 1), world, rank)
+    if src_shard.len() != 2 * count or dst_shard.len() != count:
+        raise ValueError("fold_circle_into_line: Length mismatch between src and dst after considering fold step.")
+    L.call("tstwo_fri_fold_circle_into_line_rows", dst_shard.ptrs(), src_shard.ptrs(), log_n, start, count,
+           _vp(twiddles.itwiddles.ptr), twiddles.log_size, L.u32x(as_q4(alpha)))
