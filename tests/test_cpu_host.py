@@ -31,6 +31,18 @@ def test_capi_exports_every_declared_symbol():
     assert lib.tstwo_merkle_layers_bytes(3) == 32 * 15
 
 
+def test_ts_binding_names_every_symbol():
+    """ts/backend/hip/ffi.ts (the bun:ffi stub of INTEGRATION.md) binds every symbol of the header, with as many arguments
+    as the ctypes binding has."""
+    ts = open(os.path.join(ROOT, "ts", "backend", "hip", "ffi.ts")).read()
+    for sym in L.EXPORTS:
+        m = re.search(rf"\b{sym}: \{{ args: \[([^\]]*)\]", ts)
+        assert m, f"{sym} missing from ffi.ts"
+        n_ts = len([a for a in m.group(1).split(",") if a.strip()])
+        if sym in L._SIGS:
+            assert n_ts == len(L._SIGS[sym]), (sym, n_ts, len(L._SIGS[sym]))
+
+
 def test_no_cpu_fallback_without_gpu():
     if L.device_count() > 0:
         pytest.skip("a GPU is present")

@@ -11,7 +11,16 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_init: { args: [i32], returns: i32 },
   tstwo_shutdown: { args: [], returns: i32 },
   tstwo_last_error: { args: [], returns: cstring },
+  tstwo_version: { args: [], returns: cstring },
+  tstwo_device_count: { args: [P], returns: i32 },
+  tstwo_device_name: { args: [P, u64], returns: i32 },
+  tstwo_set_stream: { args: [u64], returns: i32 },
   tstwo_sync: { args: [], returns: i32 },
+  tstwo_trim: { args: [], returns: i32 },
+  tstwo_event_create: { args: [P], returns: i32 },
+  tstwo_event_record: { args: [u64], returns: i32 },
+  tstwo_event_elapsed_ms: { args: [u64, u64, P], returns: i32 },
+  tstwo_event_destroy: { args: [u64], returns: i32 },
   tstwo_malloc: { args: [P, u64], returns: i32 },
   tstwo_free: { args: [u64], returns: i32 },
   tstwo_upload: { args: [u64, P, u64], returns: i32 },
@@ -23,6 +32,7 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_m31_mul: { args: [u64, u64, u64, u64], returns: i32 },
   tstwo_m31_neg: { args: [u64, u64, u64], returns: i32 },
   tstwo_m31_batch_inverse: { args: [u64, u64, u64], returns: i32 },
+  tstwo_cm31_batch_inverse: { args: [P, P, u64], returns: i32 },
   tstwo_qm31_batch_inverse: { args: [P, P, u64], returns: i32 },
   tstwo_qm31_mul: { args: [P, P, P, u64], returns: i32 },
   tstwo_secure_accumulate: { args: [P, P, u64], returns: i32 },
@@ -36,9 +46,12 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_fri_fold_line_tw: { args: [P, u32, u64, P, P], returns: i32 },
   tstwo_fri_fold_circle_into_line: { args: [P, u64, P, u32, u64, u32, P], returns: i32 },
   tstwo_fri_fold_circle_into_line_tw: { args: [P, u64, P, u32, u64, P], returns: i32 },
+  tstwo_fri_fold_line_rows: { args: [P, u32, u64, u64, u64, u32, P, P], returns: i32 },
+  tstwo_fri_fold_circle_into_line_rows: { args: [P, P, u32, u64, u64, u64, u32, P], returns: i32 },
   tstwo_fri_decompose: { args: [P, u64, P, P], returns: i32 },
   tstwo_merkle_commit_layer: { args: [u32, u64, P, u64, u64], returns: i32 },
   tstwo_merkle_commit: { args: [P, P, u64, u64, P], returns: i32 },
+  tstwo_merkle_layers_bytes: { args: [u32], returns: u64 },
   tstwo_gather_words: { args: [P, P, u32, u64, P], returns: i32 },
   tstwo_grind_blake2s: { args: [P, u32, u64, P], returns: i32 },
   tstwo_quotients_accumulate: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P, P, P, P], returns: i32 },
