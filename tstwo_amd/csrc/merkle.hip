@@ -252,18 +252,113 @@ __global__ void __launch_bounds__(WG) k_merkle_up(uint4 *__restrict__ layers, u3
     }
 }
 
+// ---- Upper tree, latency path: one compression spread over a QUAD of lanes (lane j of the quad owns column j of the
+// 4x4 Blake2s state).  The column step is lane-local; the diagonal step rotates rows b, c, d by 1, 2, 3 lanes with DPP
+// quad_perm moves and rotates them back.  A lane needs message words m[SIGMA[r][2j..]], i.e. a lane-dependent choice
+// among registers that are literal per round: three v_cndmask on the constant lane masks j==1, j==2, j==3.
+// ~1/2.4 of the dependent-instruction chain of the one-lane compression, which is what bounds the top of a tree.
+__device__ __forceinline__ u32 quad_rot(u32 x, int by) {   // value held by lane (j + by) & 3 of this lane's quad
+    return by == 1 ? (u32)__builtin_amdgcn_mov_dpp((int)x, 0x39, 0xF, 0xF, false)
+         : by == 2 ? (u32)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, false)
+                   : (u32)__builtin_amdgcn_mov_dpp((int)x, 0x93, 0xF, 0xF, false);
+}
+__device__ __forceinline__ u32 sel4(u32 x0, u32 x1, u32 x2, u32 x3, u32 j) {
+    u32 r = x0;
+    r = j == 1 ? x1 : r;
+    r = j == 2 ? x2 : r;
+    r = j == 3 ? x3 : r;
+    return r;
+}
+// Single 64-byte final block from the initial state (a node of children only: hashNode, vcs/blake2_merkle.ts:9-24).
+// Returns the digest words j (o_lo) and 4+j (o_hi) in lane j of the quad.
+__device__ __forceinline__ void b2s_quad_block64(const u32 (&m)[16], u32 j, u32 &o_lo, u32 &o_hi) {
+    const u32 ivlo = sel4(IV0, IV1, IV2, IV3, j), ivhi = sel4(IV4, IV5, IV6, IV7, j);
+    const u32 h_lo = ivlo ^ (j == 0 ? 0x01010020u : 0u), h_hi = ivhi;
+    u32 a = h_lo, b = h_hi, c = ivlo, d = ivhi ^ sel4(64u, 0u, 0xFFFFFFFFu, 0u, j);
+#define B2SQ_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)          \
+    {                                                                                            \
+        u32 x = sel4(m[s0], m[s2], m[s4], m[s6], j), y = sel4(m[s1], m[s3], m[s5], m[s7], j);     \
+        B2S_G(a, b, c, d, x, y);                                                                  \
+        b = quad_rot(b, 1); c = quad_rot(c, 2); d = quad_rot(d, 3);                               \
+        x = sel4(m[s8], m[s10], m[s12], m[s14], j); y = sel4(m[s9], m[s11], m[s13], m[s15], j);   \
+        B2S_G(a, b, c, d, x, y);                                                                  \
+        b = quad_rot(b, 3); c = quad_rot(c, 2); d = quad_rot(d, 1);                               \
+    }
+    B2SQ_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2SQ_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    B2SQ_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    B2SQ_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    B2SQ_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    B2SQ_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    B2SQ_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    B2SQ_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    B2SQ_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    B2SQ_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+#undef B2SQ_ROUND
+    o_lo = h_lo ^ a ^ c;
+    o_hi = h_hi ^ b ^ d;
+}
+
+// Levels log_child-1 .. log_child-levels, 4 lanes per node: a workgroup of WG lanes owns WG/4 consecutive parents of the
+// first level and everything above them (WG/4 -> 1 is log2(WG/4)+1 levels).  Children digests live in LDS between levels.
+template <int WG>
+__global__ void __launch_bounds__(WG) k_merkle_upq(uint4 *__restrict__ layers, u32 log_child, u32 levels) {
+    constexpr u32 Q = WG / 4;
+    __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];      // 2Q child digests x 8 words
+    const u32 t = threadIdx.x, q = t >> 2, j = t & 3;
+    u32 active = min(Q, 1u << (log_child - 1));                   // parents this workgroup produces at the first level
+    {
+        const uint4 *child = layers + 2 * (((size_t)1 << log_child) - 1) + (size_t)blockIdx.x * (4 * active);
+        if (t < 4 * active) reinterpret_cast<uint4 *>(sh)[t] = child[t];      // 2*active digests = 4*active uint4
+    }
+    __syncthreads();
+    for (u32 lv = 1; lv <= levels; lv++) {
+        const u32 log_out = log_child - lv;
+        u32 o_lo = 0, o_hi = 0;
+        const bool on = q < active;                                // quad-uniform
+        if (on) {
+            u32 m[16];
+            const uint4 *src = reinterpret_cast<const uint4 *>(sh) + 4 * q;
+            uint4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+            m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w; m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
+            m[8] = c2.x; m[9] = c2.y; m[10] = c2.z; m[11] = c2.w; m[12] = c3.x; m[13] = c3.y; m[14] = c3.z; m[15] = c3.w;
+            b2s_quad_block64(m, j, o_lo, o_hi);
+            u32 *out = reinterpret_cast<u32 *>(layers + 2 * (((size_t)1 << log_out) - 1) + 2 * ((size_t)blockIdx.x * active + q));
+            out[j] = o_lo;
+            out[4 + j] = o_hi;
+        }
+        __syncthreads();                                           // every quad has read its children
+        if (on) {
+            sh[8 * q + j] = o_lo;
+            sh[8 * q + 4 + j] = o_hi;
+        }
+        __syncthreads();
+        active >>= 1;
+    }
+}
+
 // Column-free levels log_child-1 .. log_stop of the tree, a few fused launches instead of one launch per level.
 int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
     Context &c = ctx();
+    static const bool one_lane = getenv("TSTWO_MERKLE_UP_ONELANE") != nullptr;     // previous scheme, kept for A/B timing
     while (log_child > log_stop) {
         const u32 remaining = log_child - log_stop;
         const u32 parents_log = log_child - 1;
-        if (parents_log >= 8) {               // >= 256 parents: 256-lane workgroups, up to 5 levels each
-            u32 levels = remaining < 5 ? remaining : 5;
-            hipLaunchKernelGGL(k_merkle_up<256>, dim3(1u << (parents_log - 8)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
+        if (one_lane) {
+            if (parents_log >= 8) {               // >= 256 parents: 256-lane workgroups, up to 5 levels each
+                u32 levels = remaining < 5 ? remaining : 5;
+                hipLaunchKernelGGL(k_merkle_up<256>, dim3(1u << (parents_log - 8)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
+                log_child -= levels;
+            } else {                              // the top of the tree (< 256 parents): one workgroup finishes it
+                hipLaunchKernelGGL(k_merkle_up<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
+                log_child -= remaining;
+            }
+        } else if (parents_log >= 6) {            // >= 64 parents: 64 quads per workgroup, 64 -> 1 = up to 7 levels each
+            u32 levels = remaining < 7 ? remaining : 7;
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1u << (parents_log - 6)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
             log_child -= levels;
-        } else {                              // the top of the tree (< 256 parents): one workgroup finishes it
-            hipLaunchKernelGGL(k_merkle_up<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
+        } else {
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
             log_child -= remaining;
         }
     }
@@ -435,6 +530,9 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
         if (log_sizes[i] > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");
         if (log_sizes[i] > max_log) max_log = log_sizes[i];
     }
+    // layers below 2^up_log nodes are latency-bound: fused multi-level launches (k_merkle_upq) instead of one per level
+    static const int up_log = getenv("TSTWO_MERKLE_UP_LOG") ? atoi(getenv("TSTWO_MERKLE_UP_LOG"))
+                              : (getenv("TSTWO_MERKLE_UP_ONELANE") ? 15 : 16);
     const u32 **lc = n_cols ? new const u32 *[n_cols] : nullptr;
     const uint8_t *prev = nullptr;
     int rc = TSTWO_OK;
@@ -445,7 +543,7 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
             if (log_sizes[i] == (u32)lg) lc[k++] = cols[i];
         uint8_t *dst = layers + 32 * (((size_t)1 << lg) - 1);
         // layer k starts at 32*(2^k-1): 16-byte aligned for every k >= 0 when `layers` is
-        if (k == 0 && prev != nullptr && lg < 15) {
+        if (k == 0 && prev != nullptr && lg < up_log) {
             // a run of column-free layers below lg+1: fuse them (stop above the next layer that has columns)
             int stop = lg;
             while (stop > 0) {

@@ -11,7 +11,7 @@ from dataclasses import dataclass, field
 from .backend import SecureColumnByCoords
 from .circle import Coset, LineDomain, bit_reverse_index
 from .queries import Queries, get_query_positions_by_log_size
-from .fields import M31, QM31
+from .fields import M31, P, QM31
 from .fri import CIRCLE_TO_LINE_FOLD_STEP, HipFriOps
 from .poly import LineEvaluation, SecureEvaluation, TwiddleTree
 from .vcs import MerkleDecommitment, MerkleProver
@@ -46,32 +46,37 @@ class FriConfig:
 def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = None) -> list:
     """LineEvaluation.interpolate + lineIfft (poly/line.ts:312-390) on the host: the last FRI layer has at most
     2^(log_last_layer_degree_bound + log_blowup_factor) elements.  Returns bit-reversed-order coefficients.
-    The x^-1 of each level are read from the tail of the inverse twiddle tree when the domain is a doubling of its
-    root (level of log size k = 2^(k-1) entries, bit-reversed); otherwise they are computed per element like the reference."""
-    vals = evaluation.values.to_vec()
-    n = len(vals)
+    Vectorised over the layer with numpy u64 (4 coordinate rows; M31 ops are coordinate-wise because every twiddle is
+    in the base field).  The x^-1 of each level are read from the tail of the inverse twiddle tree when the domain is a
+    doubling of its root (level of log size k = 2^(k-1) entries, bit-reversed); otherwise they are computed per element
+    like the reference."""
+    import numpy as np
+    P_ = np.uint64(P)
+    n = evaluation.len()
     log_n = n.bit_length() - 1
-    vals = [vals[bit_reverse_index(i, log_n)] for i in range(n)]
+    br = np.array([bit_reverse_index(i, log_n) for i in range(n)], dtype=np.int64)
+    vals = np.stack([c.astype(np.uint64) for c in evaluation.values.to_numpy()])[:, br]       # (4, n), natural order
     domain = evaluation.domain()
     tail = None
     if twiddles is not None and log_n >= 1 and domain.coset().is_doubling_of(twiddles.rootCoset):
         L_ = twiddles.itwiddles.len()
-        tail = twiddles.itwiddles.buf.download(count=n, offset=4 * (L_ - n))        # last n entries of the tree
+        tail = twiddles.itwiddles.buf.download(count=n, offset=4 * (L_ - n))                  # last n entries of the tree
     while domain.size() > 1:
         size, half = domain.size(), domain.size() // 2
         k = domain.logSize()
         if tail is not None:
-            seg = tail[n - size:n - half]                                            # tree[L - 2^k : L - 2^(k-1)]
-            inv = [M31(int(seg[bit_reverse_index(i, k - 1)])) for i in range(half)]
+            seg = tail[n - size:n - half]                                                     # tree[L - 2^k : L - 2^(k-1)]
+            inv = seg[[bit_reverse_index(i, k - 1) for i in range(half)]].astype(np.uint64)
         else:
-            inv = [domain.at(i).inverse() for i in range(half)]
-        for start in range(0, n, size):
-            for i in range(half):
-                a, b = vals[start + i], vals[start + i + half]
-                vals[start + i], vals[start + i + half] = a.add(b), a.sub(b).mulM31(inv[i])    # ibutterfly (fft.ts:25-30)
+            inv = np.array([domain.at(i).inverse().value for i in range(half)], dtype=np.uint64)
+        v = vals.reshape(4, n // size, 2, half)
+        a, b = v[:, :, 0, :], v[:, :, 1, :]
+        s_, d_ = (a + b) % P_, ((a + P_ - b) % P_) * inv % P_                                  # ibutterfly (fft.ts:25-30)
+        vals = np.stack([s_, d_], axis=2).reshape(4, n)
         domain = domain.double()
-    len_inv = M31.from_(n).inverse()
-    return [v.mulM31(len_inv) for v in vals]
+    len_inv = np.uint64(M31.from_(n).inverse().value)
+    vals = vals * len_inv % P_
+    return [QM31.from_u32_unchecked(*(int(vals[c, i]) for c in range(4))) for i in range(n)]
 
 
 class LinePoly:
