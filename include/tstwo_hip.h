@@ -151,6 +151,17 @@ int tstwo_merkle_commit_layer(uint32_t log_size, const uint8_t *prev, const uint
 int tstwo_merkle_commit(const uint32_t *const *cols, const uint32_t *log_sizes, size_t n_cols,
                         uint8_t *layers, uint8_t root[32]);
 size_t tstwo_merkle_layers_bytes(uint32_t max_log);
+/* MerkleProver.decommit (vcs/prover.ts:32-109) on a tree built by tstwo_merkle_commit: `layers` is that call's buffer,
+ * `cols` / `col_log_sizes` the same columns in the same order.  Query set k = n_queries[k] ascending positions
+ * queries[k][] (host) into the layer of log size query_logs[k].  Outputs (host): the queried column values (layer by
+ * layer from the largest, node by node, column by column — the order MerkleVerifier.verify consumes), the hash
+ * witness (32 bytes each) and the column witness.  The three size_t are in/out: capacity in elements on entry, count on
+ * return; if a buffer is too small the counts are returned with TSTWO_ERR_BAD_ARG and nothing is written. */
+int tstwo_merkle_decommit(const uint8_t *layers, uint32_t max_log, const uint32_t *const *cols,
+                          const uint32_t *col_log_sizes, size_t n_cols, const uint32_t *query_logs,
+                          const uint64_t *const *queries, const size_t *n_queries, size_t n_query_sets,
+                          uint32_t *queried_values, size_t *n_queried, uint8_t *hash_witness, size_t *n_hashes,
+                          uint32_t *column_witness, size_t *n_column_witness);
 /* Gather for MerkleProver.decommit (vcs/prover.ts:32-109): item i = `words` consecutive uint32 words starting at
  * word index idx[i]*words of the device buffer srcs[i] (a column: words = 1; a layer of digests: words = 8).
  * Results land contiguously in host_out (n_items * words words).  srcs / idx are host arrays.  Synchronises. */

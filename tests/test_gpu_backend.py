@@ -373,6 +373,28 @@ def test_merkle_decommit_large():
     values, dec = tree.decommit(queries, cols)
     T.MerkleVerifier(T.Blake2sMerkleHasher(), tree.root(), log_sizes).verify(queries, values, dec)
     assert len(dec.hashWitness) > 0 and all(len(h) == 32 for h in dec.hashWitness)
+    # the in-library walk (tstwo_merkle_decommit) == the reference's walk on the host mirror
+    v2, d2 = tree._decommit_walk(queries, cols)
+    assert [v.value for v in values] == [v.value for v in v2]
+    assert dec.hashWitness == d2.hashWitness and [v.value for v in dec.columnWitness] == [v.value for v in d2.columnWitness]
+
+
+def test_merkle_decommit_capi_capacity_and_errors():
+    """tstwo_merkle_decommit: too-small buffers return the required counts; out-of-layer queries are rejected."""
+    cols = [T.HipColumn(rand_column(350 + i, 1 << 6)) for i in range(3)]
+    tree = T.MerkleProver.commit(cols)
+    q = (C.c_uint64 * 2)(3, 40)
+    qp = (C.POINTER(C.c_uint64) * 1)(C.cast(q, C.POINTER(C.c_uint64)))
+    nq = (C.c_size_t * 1)(2)
+    n_q, n_h, n_w = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    args = lambda: (C.c_void_p(tree._buf.ptr), 6, L.ptr_array([c.ptr for c in cols]), L.u32x([6, 6, 6]), 3, L.u32x([6]), qp, nq, 1,
+                    None, C.byref(n_q), None, C.byref(n_h), None, C.byref(n_w))
+    with pytest.raises(L.TstwoError, match="output buffer too small"):
+        L.call("tstwo_merkle_decommit", *args())
+    assert (n_q.value, n_w.value) == (6, 0) and n_h.value == len(tree.decommit({6: [3, 40]}, cols)[1].hashWitness)
+    q[1] = 64
+    with pytest.raises(L.TstwoError, match="outside its layer"):
+        L.call("tstwo_merkle_decommit", *args())
 
 
 # ---------------------------------------------------------------- fri.test.ts: FriProver.commit (real Merkle + channel wiring)

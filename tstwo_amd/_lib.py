@@ -72,6 +72,9 @@ _SIGS = {
     "tstwo_merkle_commit_layer": [C.c_uint32, vp, C.POINTER(vp), C.c_size_t, vp],
     "tstwo_merkle_commit": [C.POINTER(vp), u32p, C.c_size_t, vp, u8p],
     "tstwo_grind_blake2s": [u8p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)],
+    "tstwo_merkle_decommit": [vp, C.c_uint32, C.POINTER(vp), u32p, C.c_size_t, u32p, C.POINTER(C.POINTER(C.c_uint64)),
+                              C.POINTER(C.c_size_t), C.c_size_t, u32p, C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_size_t),
+                              u32p, C.POINTER(C.c_size_t)],
     "tstwo_gather_words": [C.POINTER(vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_size_t, u32p],
     "tstwo_quotients_accumulate": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,
                                    u32p, u32p, u32p, u32p, u32p, P4],

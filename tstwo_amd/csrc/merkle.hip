@@ -8,6 +8,8 @@
 // The compression is VALU-bound (~1.2k lane-ops per 64-byte block, ~19 ops/byte) — DESIGN.md §Merkle
 // prices it against the integer-issue ceiling as well as the HBM roofline the bench reports.
 // Algorithmic bytes for a layer of n nodes: 4*C*n (+ 64*n children) read, 32*n written.
+#include <vector>
+
 #include "common.h"
 #include <stdlib.h>
 
@@ -513,6 +515,76 @@ int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, u32 words, 
     TSTWO_LAUNCH_CHECK();
     TSTWO_HIP(hipMemcpyAsync(host_out, d_out, total * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
     TSTWO_HIP(hipStreamSynchronize(c.stream));
+    return TSTWO_OK;
+}
+
+// MerkleProver.decommit (vcs/prover.ts:32-109) against device-resident layers and columns: the walk over the layers
+// (which nodes are visited, which child digests / column values the verifier cannot recompute) runs here on the host
+// side of the library; the selected words are then fetched with two gathers.
+int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *cols, const u32 *col_log_sizes, size_t n_cols,
+                          const u32 *query_logs, const uint64_t *const *queries, const size_t *n_queries, size_t n_query_sets,
+                          u32 *queried_values, size_t *n_queried, uint8_t *hash_witness, size_t *n_hashes,
+                          u32 *column_witness, size_t *n_column_witness) {
+    TSTWO_REQUIRE_READY();
+    if (!layers || !n_queried || !n_hashes || !n_column_witness || (n_cols && (!cols || !col_log_sizes)) ||
+        (n_query_sets && (!query_logs || !queries || !n_queries)))
+        return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: null argument");
+    if (max_log > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");
+    for (size_t i = 0; i < n_cols; i++)
+        if (col_log_sizes[i] > max_log) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: column larger than the tree");
+    std::vector<const void *> h_src, q_src, w_src;
+    std::vector<uint64_t> h_idx, q_idx, w_idx;
+    std::vector<uint64_t> last, cur;
+    for (int lg = (int)max_log; lg >= 0; lg--) {
+        const uint64_t *direct = nullptr;
+        size_t nd = 0;
+        for (size_t k = 0; k < n_query_sets; k++)
+            if (query_logs[k] == (u32)lg) { direct = queries[k]; nd = n_queries[k]; }
+        for (size_t k = 0; k < nd; k++)
+            if (direct[k] >> lg) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: query position outside its layer");
+        const bool has_child = (u32)lg < max_log;
+        const uint8_t *child_layer = has_child ? layers + 32 * (((size_t)1 << (lg + 1)) - 1) : nullptr;
+        size_t pi = 0, di = 0;
+        cur.clear();
+        for (;;) {
+            bool any = false;
+            uint64_t node = 0;
+            if (pi < last.size()) { node = last[pi] >> 1; any = true; }
+            if (di < nd && (!any || direct[di] < node)) { node = direct[di]; any = true; }
+            if (!any) break;
+            if (has_child)
+                for (uint64_t k = 2 * node; k <= 2 * node + 1; k++) {
+                    if (pi < last.size() && last[pi] == k) pi++;
+                    else { h_src.push_back(child_layer); h_idx.push_back(k); }
+                }
+            const bool queried = di < nd && direct[di] == node;
+            if (queried) di++;
+            for (size_t i = 0; i < n_cols; i++)          // columns of this layer, in the caller's order (stable sort by size)
+                if (col_log_sizes[i] == (u32)lg) {
+                    (queried ? q_src : w_src).push_back(cols[i]);
+                    (queried ? q_idx : w_idx).push_back(node);
+                }
+            cur.push_back(node);
+        }
+        last.swap(cur);
+    }
+    const size_t cap_q = *n_queried, cap_h = *n_hashes, cap_w = *n_column_witness;
+    *n_queried = q_src.size(); *n_hashes = h_src.size(); *n_column_witness = w_src.size();
+    if (q_src.size() > cap_q || h_src.size() > cap_h || w_src.size() > cap_w ||
+        (q_src.size() && !queried_values) || (h_src.size() && !hash_witness) || (w_src.size() && !column_witness))
+        return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: output buffer too small (required counts returned)");
+    int rc = tstwo_gather_words(h_src.data(), h_idx.data(), 8, h_src.size(), (u32 *)hash_witness);
+    if (rc) return rc;
+    // queried values and column witness share one launch: gather into a temporary, then split
+    std::vector<const void *> v_src(q_src);
+    v_src.insert(v_src.end(), w_src.begin(), w_src.end());
+    std::vector<uint64_t> v_idx(q_idx);
+    v_idx.insert(v_idx.end(), w_idx.begin(), w_idx.end());
+    std::vector<u32> vals(v_src.size());
+    rc = tstwo_gather_words(v_src.data(), v_idx.data(), 1, v_src.size(), vals.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < q_src.size(); i++) queried_values[i] = vals[i];
+    for (size_t i = 0; i < w_src.size(); i++) column_witness[i] = vals[q_src.size() + i];
     return TSTWO_OK;
 }
 

@@ -75,8 +75,34 @@ class MerkleProver:
 
     def decommit(self, queriesPerLogSize: dict, columns) -> tuple:
         """MerkleProver.decommit (vcs/prover.ts:32-109): returns (queried_values, MerkleDecommitment).
-        The walk over the layers is the reference's; the digests / column words it selects are fetched from the
-        device-resident layers and columns with two gathers (tstwo_gather_words) instead of per-element reads."""
+        The walk over the layers and the two device gathers run inside the library (tstwo_merkle_decommit);
+        `_decommit_walk` below is the same walk on the host mirror, kept for cross-checking."""
+        cols = list(columns)
+        max_log = len(self.layers) - 1
+        sets = [(lg, list(q)) for lg, q in queriesPerLogSize.items() if q]
+        for lg, _ in sets:
+            if lg > max_log or lg < 0:
+                raise ValueError("query log size outside the tree")
+        total_q = sum(len(q) for _, q in sets)
+        cap_v = max(1, total_q * max(1, len(cols)))
+        cap_h = max(1, 2 * total_q * (max_log + 1))
+        qarrs = [(C.c_uint64 * max(len(q), 1))(*q) for _, q in sets]
+        qptrs = (C.POINTER(C.c_uint64) * max(len(sets), 1))(*[C.cast(a, C.POINTER(C.c_uint64)) for a in qarrs])
+        nq = (C.c_size_t * max(len(sets), 1))(*[len(q) for _, q in sets])
+        queried = np.empty(cap_v, dtype=np.uint32)
+        colwit = np.empty(cap_v, dtype=np.uint32)
+        hashes = np.empty(32 * cap_h, dtype=np.uint8)
+        n_q, n_h, n_w = C.c_size_t(cap_v), C.c_size_t(cap_h), C.c_size_t(cap_v)
+        L.call("tstwo_merkle_decommit", _vp(self._buf.ptr), max_log, L.ptr_array([c.ptr for c in cols]),
+               L.u32x([c.len().bit_length() - 1 for c in cols]), len(cols), L.u32x([lg for lg, _ in sets]), qptrs, nq, len(sets),
+               queried.ctypes.data_as(L.u32p), C.byref(n_q), hashes.ctypes.data_as(L.u8p), C.byref(n_h),
+               colwit.ctypes.data_as(L.u32p), C.byref(n_w))
+        hb = hashes.tobytes()
+        dec = MerkleDecommitment([hb[32 * i:32 * i + 32] for i in range(n_h.value)], [M31(int(v)) for v in colwit[:n_w.value]])
+        return [M31(int(v)) for v in queried[:n_q.value]], dec
+
+    def _decommit_walk(self, queriesPerLogSize: dict, columns) -> tuple:
+        """The reference's walk (vcs/prover.ts:32-109) on the host mirror + two tstwo_gather_words calls."""
         sorted_cols = sorted(columns, key=lambda c: -c.len())                 # stable, like the JS sort
         col_i = 0
         hash_req, queried_req, witness_req = [], [], []                       # (device ptr, index) requests, in order
