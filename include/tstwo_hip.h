@@ -107,6 +107,11 @@ int tstwo_poly_extend(const uint32_t *src, uint32_t log_src, uint32_t *dst, uint
 /* PolyOps.eval_at_point (circle.ts:52-69): point and result are QM31 as 4 host words. */
 int tstwo_eval_at_point(const uint32_t *coeffs, uint32_t log_size, const uint32_t point_x[4],
                         const uint32_t point_y[4], uint32_t out[4]);
+/* The same for n_cols polynomials of one size at one point (prove_values samples every column of a tree at the same
+ * out-of-domain point): one launch sequence and one read-back.  coeffs: host array of device pointers; out: 4 words per
+ * column (host). */
+int tstwo_eval_at_point_batch(const uint32_t *const *coeffs, size_t n_cols, uint32_t log_size, const uint32_t px[4],
+                              const uint32_t py[4], uint32_t *out);
 
 /* ---------------------------------------------------------------- FriOps (fri.ts:93-110)
  * Twiddles come from the inverse twiddle tree `itw` (root coset log tw_log) — a FRI fold is one

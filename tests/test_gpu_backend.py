@@ -708,13 +708,27 @@ def test_pcs_verify_rejects_bad_proofs():
     # claiming a sampled value the polynomial does not take: the prover itself cannot produce a low-degree quotient
     scheme2, ch2 = _pcs_setup(config, logs, seed=12000)
     p2 = T.CirclePoint.get_random_point(ch2)
-    orig = T.HipCirclePoly.eval_at_point
+    orig = T.HipCirclePoly.eval_at_point_batch
     try:
-        T.HipCirclePoly.eval_at_point = staticmethod(lambda poly, pt: orig(poly, pt).add(T.QM31.one()))
+        T.HipCirclePoly.eval_at_point_batch = staticmethod(lambda polys, pt: [v.add(T.QM31.one()) for v in orig(polys, pt)])
         with pytest.raises(ValueError, match="invalid degree"):
             scheme2.prove_values([[[p2], [p2]]], ch2)
     finally:
-        T.HipCirclePoly.eval_at_point = staticmethod(orig)
+        T.HipCirclePoly.eval_at_point_batch = staticmethod(orig)
+
+
+def test_eval_at_point_batch_matches_single():
+    """tstwo_eval_at_point_batch == tstwo_eval_at_point per polynomial == the oracle (sizes straddling the 2^5 fold chunks,
+    more than 64 columns so the batch is split)."""
+    pt = T.SECURE_FIELD_CIRCLE_GEN.add(T.SECURE_FIELD_CIRCLE_GEN)
+    for lg, n in ((1, 3), (4, 2), (5, 5), (6, 3), (11, 70), (16, 4)):
+        cols = [rand_column(14000 + 10 * lg + i, 1 << lg) for i in range(n)]
+        polys = [T.HipCirclePoly(c) for c in cols]
+        got = T.HipCirclePoly.eval_at_point_batch(polys, pt)
+        assert [g.tup() for g in got] == [p.evalAtPoint(pt).tup() for p in polys]
+        assert got[0].tup() == tuple(orc.eval_at_point(cols[0], lg, pt.x.tup(), pt.y.tup()))
+    with pytest.raises(ValueError, match="one size"):
+        T.HipCirclePoly.eval_at_point_batch([T.HipCirclePoly(rand_column(1, 4)), T.HipCirclePoly(rand_column(2, 8))], pt)
 
 
 def test_fri_answers_match_device_quotients():

@@ -6,6 +6,8 @@
 // twiddle tree.  One lane per output row on SoA QM31 (4 coalesced 8-byte loads, 4 coalesced stores).
 // Algorithmic bytes per output row: fold_line 48 (32 in + 16 out), fold_circle_into_line 64
 // (32 src + 16 dst in + 16 dst out).
+#include <vector>
+
 #include "common.h"
 #include "host_field.h"
 
@@ -97,6 +99,35 @@ __global__ void __launch_bounds__(256) k_fold_chunk(const u32 *__restrict__ coef
                                                    qm31 *__restrict__ partial_out, size_t n_out, int S, FoldFactors ff) {
     size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_out) return;
+    qm31 v[32];
+    const int cnt = 1 << S;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (j < cnt) {
+            if (FIRST) v[j] = qm31_from_m31(coeffs[(o << S) + j]);
+            else v[j] = partial_in[(o << S) + j];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        if (s < S) {
+#pragma unroll
+            for (int j = 0; j < (16 >> s); j++)
+                if (j < (cnt >> (s + 1))) v[j] = qm31_add(v[2 * j], qm31_mul(v[2 * j + 1], ff.f[s]));
+        }
+    }
+    partial_out[o] = v[0];
+}
+
+// Same fold for up to 64 columns of one size at one point: blockIdx.y = column; partial buffers are column-strided.
+template <bool FIRST>
+__global__ void __launch_bounds__(256) k_fold_chunk_batch(ColPtrs cols, const qm31 *__restrict__ partial_in, size_t in_stride,
+                                                         qm31 *__restrict__ partial_out, size_t out_stride, size_t n_out, int S, FoldFactors ff) {
+    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    const u32 *__restrict__ coeffs = cols.p[blockIdx.y];
+    partial_in += (size_t)blockIdx.y * in_stride;
+    partial_out += (size_t)blockIdx.y * out_stride;
     qm31 v[32];
     const int cnt = 1 << S;
 #pragma unroll
@@ -311,6 +342,72 @@ int tstwo_eval_at_point(const u32 *coeffs, u32 log_size, const u32 px[4], const 
     TSTWO_HIP(hipMemcpyAsync(&r, src, sizeof(r), hipMemcpyDeviceToHost, c.stream));
     TSTWO_HIP(hipStreamSynchronize(c.stream));
     out[0] = r.a; out[1] = r.b; out[2] = r.c; out[3] = r.d;
+    return TSTWO_OK;
+}
+
+// eval_at_point of n_cols polynomials of one size at one point (CommitmentSchemeProver.prove_values samples every
+// column of a tree at the same out-of-domain point, pcs/prover.ts Rust text :93-110): one launch sequence and one
+// read-back for all of them.  out = 4 words per column.
+int tstwo_eval_at_point_batch(const u32 *const *coeffs, size_t n_cols, u32 log_size, const u32 px[4], const u32 py[4], u32 *out) {
+    TSTWO_REQUIRE_READY();
+    if (n_cols == 0) return TSTWO_OK;
+    if (!coeffs || !out) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: null argument");
+    if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: log size out of range");
+    if (log_size == 0 || n_cols == 1) {
+        for (size_t i = 0; i < n_cols; i++) {
+            int rc = tstwo_eval_at_point(coeffs[i], log_size, px, py, out + 4 * i);
+            if (rc) return rc;
+        }
+        return TSTWO_OK;
+    }
+    Context &c = ctx();
+    host::Q fac[32];
+    fac[0] = to_hq(py);
+    host::Q x = to_hq(px), one;
+    one.v[0] = 1; one.v[1] = one.v[2] = one.v[3] = 0;
+    for (u32 i = 1; i < log_size; i++) {
+        fac[i] = x;
+        host::Q sx = host::qmul(x, x);
+        x = host::qsub(host::qadd(sx, sx), one);
+    }
+    const size_t n1 = (size_t)1 << (log_size > 5 ? log_size - 5 : 0);
+    const size_t stride = n1 + 32;
+    for (size_t base = 0; base < n_cols; base += 64) {
+        const size_t g = n_cols - base < 64 ? n_cols - base : 64;
+        int rc = ensure_scratch(2 * g * stride * sizeof(qm31));
+        if (rc) return rc;
+        ColPtrs cp;
+        for (size_t i = 0; i < 64; i++) cp.p[i] = const_cast<u32 *>(coeffs[base + (i < g ? i : 0)]);
+        qm31 *bufA = (qm31 *)c.scratch, *bufB = bufA + g * stride;
+        u32 done = 0;
+        size_t cur = (size_t)1 << log_size;
+        bool first = true;
+        qm31 *src = nullptr, *dst = bufA;
+        while (done < log_size) {
+            int S = (int)(log_size - done < 5 ? log_size - done : 5);
+            size_t n_out = cur >> S;
+            FoldFactors ff;
+            for (int s = 0; s < 5; s++) ff.f[s] = s < S ? to_q(fac[done + s]) : qm31{0, 0, 0, 0};
+            dim3 grid(ceil_div(n_out, 256), (unsigned)g);
+            if (first)
+                hipLaunchKernelGGL(k_fold_chunk_batch<true>, grid, dim3(256), 0, c.stream, cp, (const qm31 *)bufA, stride, dst, stride, n_out, S, ff);
+            else
+                hipLaunchKernelGGL(k_fold_chunk_batch<false>, grid, dim3(256), 0, c.stream, cp, (const qm31 *)src, stride, dst, stride, n_out, S, ff);
+            first = false;
+            done += (u32)S;
+            cur = n_out;
+            src = dst;
+            dst = (dst == bufA) ? bufB : bufA;
+        }
+        TSTWO_LAUNCH_CHECK();
+        std::vector<qm31> r(g);
+        TSTWO_HIP(hipMemcpy2DAsync(r.data(), sizeof(qm31), src, stride * sizeof(qm31), sizeof(qm31), g, hipMemcpyDeviceToHost, c.stream));
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        for (size_t i = 0; i < g; i++) {
+            u32 *o = out + 4 * (base + i);
+            o[0] = r[i].a; o[1] = r[i].b; o[2] = r[i].c; o[3] = r[i].d;
+        }
+    }
     return TSTWO_OK;
 }
 

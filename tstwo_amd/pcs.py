@@ -155,8 +155,21 @@ class CommitmentSchemeProver:
         Out-of-domain evaluation, quotients, FRI commit, grinding and every decommitment read device-resident data;
         only sampled values, roots, witnesses and queried values reach the host."""
         # "Evaluate columns out of domain"
-        samples = [[[PointSample(pt, poly.evalAtPoint(pt)) for pt in pts] for poly, pts in zip(tree.polynomials, tree_pts)]
-                   for tree, tree_pts in zip(self.trees, sampled_points)]
+        # (all polynomials of one size sampled at the same point share one batched launch sequence)
+        groups = {}
+        for ti, (tree, tree_pts) in enumerate(zip(self.trees, sampled_points)):
+            if len(tree_pts) != len(tree.polynomials):
+                raise ValueError("sampled_points does not match the committed columns")
+            for ci, (poly, pts) in enumerate(zip(tree.polynomials, tree_pts)):
+                for pi, pt in enumerate(pts):
+                    key = (poly.logSize(), pt.x.tup(), pt.y.tup())
+                    groups.setdefault(key, (pt, []))[1].append((ti, ci, pi, poly))
+        values = {}
+        for pt, members in groups.values():
+            for (ti, ci, pi, _), v in zip(members, HipCirclePoly.eval_at_point_batch([m[3] for m in members], pt)):
+                values[(ti, ci, pi)] = v
+        samples = [[[PointSample(pt, values[(ti, ci, pi)]) for pi, pt in enumerate(pts)] for ci, pts in enumerate(tree_pts)]
+                   for ti, tree_pts in enumerate(sampled_points)]
         sampled_values = [[[s.value for s in col] for col in tree] for tree in samples]
         channel.mix_felts([v for tree in sampled_values for col in tree for v in col])
         # OODS quotients over every tree's evaluations, flattened

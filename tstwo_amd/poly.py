@@ -82,6 +82,21 @@ class HipCirclePoly:
         return QM31.from_u32_unchecked(*out)
 
     @staticmethod
+    def eval_at_point_batch(polys, point: CirclePoint) -> list:
+        """eval_at_point of several polynomials of ONE size at one point: one launch sequence, one read-back
+        (tstwo_eval_at_point_batch).  Same values as [p.evalAtPoint(point) for p in polys]."""
+        polys = list(polys)
+        if not polys:
+            return []
+        lg = polys[0].logSize()
+        if any(p.logSize() != lg for p in polys):
+            raise ValueError("eval_at_point_batch: polynomials must have one size")
+        out = (C.c_uint32 * (4 * len(polys)))()
+        L.call("tstwo_eval_at_point_batch", L.ptr_array([p.coeffs.ptr for p in polys]), len(polys), lg,
+               L.u32x(as_q4(point.x)), L.u32x(as_q4(point.y)), out)
+        return [QM31.from_u32_unchecked(*out[4 * i:4 * i + 4]) for i in range(len(polys))]
+
+    @staticmethod
     def extend_static(poly: "HipCirclePoly", log_size: int) -> "HipCirclePoly":
         if log_size < poly.logSize():
             raise ValueError("log size too small")
