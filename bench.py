@@ -147,8 +147,12 @@ def main():
     L.call("tstwo_twiddles_build", half_initial, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
     layers = L.DeviceBuffer(32 * ((2 << n) - 1))
     log_sizes = L.u32x([n] * n_cols)
-    roots_local = torch.zeros(32, dtype=torch.uint8, device=root_dev)
-    roots_all = torch.zeros(32 * world, dtype=torch.uint8, device=root_dev)
+    # two root slots: the all-gather of step k (async on RCCL's stream) overlaps the CFFT of step k+1, so slot k%2 is
+    # rewritten only after the collective that read it (step k-2's... see `pending`) has been waited for
+    roots_local = [torch.zeros(32, dtype=torch.uint8, device=root_dev) for _ in range(2)]
+    roots_all = [torch.zeros(32 * world, dtype=torch.uint8, device=root_dev) for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
     L.sync()
 
     # HIP events on the library's stream, three per timed step, read after the timed region
@@ -164,13 +168,25 @@ def main():
         if ev:
             ev[2].record()
         if use_dist:   # the only exchange on the path: 32-byte roots over RCCL/xGMI
+            k = step_no[0] & 1
+            step_no[0] += 1
+            if pending[k] is not None:
+                pending[k].wait()          # stream-side wait (nccl) / host wait (gloo) for the collective that used slot k
             if root_dev == "cuda":
-                L.call("tstwo_copy", C.c_void_p(roots_local.data_ptr()), C.c_void_p(layers.ptr), 32)
+                L.call("tstwo_copy", C.c_void_p(roots_local[k].data_ptr()), C.c_void_p(layers.ptr), 32)
             else:
-                L.call("tstwo_download", C.c_void_p(roots_local.data_ptr()), C.c_void_p(layers.ptr), 32)
-            dist.all_gather_into_tensor(roots_all, roots_local)
+                L.call("tstwo_download", C.c_void_p(roots_local[k].data_ptr()), C.c_void_p(layers.ptr), 32)
+            pending[k] = dist.all_gather_into_tensor(roots_all[k], roots_local[k], async_op=True)
+
+    def drain():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     def barrier():
+        if use_dist:
+            drain()
         L.sync()
         torch.cuda.synchronize()
         if use_dist:
@@ -194,7 +210,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # roots of all ranks must have arrived and rank r's slot must hold rank r's root
-        mine = bytes(roots_all[32 * rank:32 * rank + 32].cpu().numpy().tobytes())
+        last = (step_no[0] - 1) & 1
+        mine = bytes(roots_all[last][32 * rank:32 * rank + 32].cpu().numpy().tobytes())
         assert mine == bytes(layers.download(np.uint8, 32).tobytes())
 
     if rank == 0:
