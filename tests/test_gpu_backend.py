@@ -782,6 +782,47 @@ def test_line_interpolate_with_and_without_tree():
     assert [x.tup() for x in a] == [x.tup() for x in b]
 
 
+# ---------------------------------------------------------------- poly/circle/secure_poly.ts, poly.ts:56-73, poly/utils.ts:78-100
+def test_secure_circle_poly_roundtrip_and_eval():
+    LOG = 7
+    domain = T.CanonicCoset(LOG + 1).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    coeffs = [rand_column(16000 + k, 1 << LOG) for k in range(4)]
+    sp = T.SecureCirclePoly([T.HipCirclePoly(c) for c in coeffs])
+    assert sp.logSize() == LOG and len(sp.intoCoordinatePolys()) == 4
+    ev = sp.evaluateWithTwiddles(domain, tw)
+    assert isinstance(ev, T.SecureEvaluation) and ev.len() == 1 << (LOG + 1)
+    back = ev.interpolateWithTwiddles(tw)
+    assert isinstance(back, T.SecureCirclePoly)
+    for c, p in zip(coeffs, back):
+        got = p.coeffs.to_numpy()
+        assert (got[:1 << LOG] == c).all() and not got[1 << LOG:].any()
+        assert p.isInFftSpace(LOG) and p.isInFriSpace(LOG) and not p.isInFftSpace(LOG - 1)
+    pt = T.SECURE_FIELD_CIRCLE_GEN
+    cols = sp.evalColumnsAtPoint(pt)
+    assert [c.tup() for c in cols] == [tuple(orc.eval_at_point(c, LOG, pt.x.tup(), pt.y.tup())) for c in coeffs]
+    assert sp.evalAtPoint(pt).tup() == T.QM31.from_partial_evals(cols).tup()
+    assert sp.evalAtPoint(pt, ts_compat=True).tup() == cols[0].tup()        # the TS port's coordinate-0 behaviour
+    # a value of the secure evaluation is the polynomial at that domain point
+    i = 37
+    p_i = domain.at(T.bit_reverse_index(i, LOG + 1))
+    as_q = T.CirclePoint(T.QM31.from_(p_i.x), T.QM31.from_(p_i.y))
+    assert ev.values.at(i).tup() == sp.evalAtPoint(as_q).tup()
+    with pytest.raises(ValueError, match="4 coordinate"):
+        T.SecureCirclePoly([T.HipCirclePoly(coeffs[0])])
+
+
+def test_domain_line_twiddles_from_tree_kat():
+    """test/poly/domainLineTwiddles.test.ts:7-13: buffer [0..7], domain of log 3 -> [[4,5,6,7]... slices from the end."""
+    buf = T.HipColumn(np.arange(8, dtype=np.uint32))
+    dom = T.LineDomain(T.Coset.half_odds(3))
+    views = T.domain_line_twiddles_from_tree(dom, buf)
+    host = buf.to_numpy()
+    assert [list(host[o:o + n]) for o, n in views] == [[0, 1, 2, 3], [4, 5], [6]]
+    with pytest.raises(ValueError, match="Not enough twiddles!"):
+        T.domain_line_twiddles_from_tree(T.LineDomain(T.Coset.half_odds(4)), buf)
+
+
 # ---------------------------------------------------------------- SURVEY 8(e): row sharding of FRI layers / one big tree
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_row_sharded_fold_and_commit_match_single_gpu(world):

@@ -20,7 +20,8 @@ from .pcs import (CommitmentSchemeProof, CommitmentSchemeProver, CommitmentTreeP
                   TreeBuilder, column_sample_batches, compute_fri_quotients)
 from .pcs_verifier import (CommitmentSchemeVerifier, VerificationError, accumulate_row_quotients,  # noqa: F401
                            fri_answers)
-from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureEvaluation, TwiddleTree,  # noqa: F401
+from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureCirclePoly, SecureEvaluation, TwiddleTree,
+                   domain_line_twiddles_from_tree,  # noqa: F401
                    evaluate_polynomials, interpolate_columns, precompute_twiddles)
 from .quotients import (ColumnSampleBatch, accumulate, accumulateQuotients, generate_secure_powers,  # noqa: F401
                         quotientConstants)

@@ -404,7 +404,8 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
     const u32 child_words = prev ? 16u : 0u;
     const u32 W = child_words + (u32)n_cols;
     unsigned blocks = ceil_div(n_nodes, 256);
-    const unsigned cap = (unsigned)c.n_cus * 8 * 4;        // 8 workgroups per CU x 4 nodes per lane before grid-striding more
+    static const unsigned cap_mult = getenv("TSTWO_MERKLE_CAP") ? (unsigned)atoi(getenv("TSTWO_MERKLE_CAP")) : 32u;
+    const unsigned cap = (unsigned)c.n_cus * cap_mult;     // workgroups per CU before lanes grid-stride over more nodes
     if (blocks > cap) blocks = cap;
     if (!prev && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !getenv("TSTWO_MERKLE_GENERIC")) {
         HashColPtrs hp;

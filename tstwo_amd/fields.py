@@ -132,6 +132,14 @@ class QM31:
         return QM31(CM31(m, M31.zero()), CM31(M31.zero(), M31.zero()))
 
     @staticmethod
+    def from_partial_evals(evals) -> "QM31":
+        """qm31.ts:168-174: sum_k evals[k] * basis_k with basis (1, i, u, iu)."""
+        res = evals[0]
+        for k, e in enumerate(evals[1:], 1):
+            res = res.add(e.mul(QM31.from_u32_unchecked(*[1 if j == k else 0 for j in range(4)])))
+        return res
+
+    @staticmethod
     def zero(): return QM31.from_u32_unchecked(0, 0, 0, 0)
     @staticmethod
     def one(): return QM31.from_u32_unchecked(1, 0, 0, 0)

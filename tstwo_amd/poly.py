@@ -96,6 +96,21 @@ class HipCirclePoly:
                L.u32x(as_q4(point.x)), L.u32x(as_q4(point.y)), out)
         return [QM31.from_u32_unchecked(*out[4 * i:4 * i + 4]) for i in range(len(polys))]
 
+    def _n_significant(self) -> int:
+        c = self.coeffs.to_numpy()
+        nz = np.flatnonzero(c)
+        return int(nz[-1]) + 1 if nz.size else 0
+
+    def isInFftSpace(self, log_fft_size: int) -> bool:
+        """poly.ts:56-63: at most 2^log_fft_size leading coefficients are non-zero."""
+        return self._n_significant() <= (1 << log_fft_size)
+
+    def isInFriSpace(self, log_fft_size: int) -> bool:
+        """poly.ts:66-73 (is_in_fri_space): one more coefficient than the FFT space."""
+        return self._n_significant() <= (1 << log_fft_size) + 1
+
+    is_in_fft_space, is_in_fri_space = isInFftSpace, isInFriSpace
+
     @staticmethod
     def extend_static(poly: "HipCirclePoly", log_size: int) -> "HipCirclePoly":
         if log_size < poly.logSize():
@@ -191,9 +206,69 @@ class SecureEvaluation:
 
     def len(self): return self.values.len()
 
-    def interpolateWithTwiddles(self, twiddles) -> list:
-        """SecureCirclePoly = 4 coordinate polys (secure_poly.ts:73-80)."""
-        return interpolate_columns([HipCircleEvaluation(self.domain, c) for c in self.values.columns], twiddles)
+    def intoCoordinateEvals(self) -> list:
+        """secure_poly.ts:61-64."""
+        return [HipCircleEvaluation(self.domain, c) for c in self.values.columns]
+
+    def interpolateWithTwiddles(self, twiddles) -> "SecureCirclePoly":
+        """secure_poly.ts:73-80: the 4 coordinate columns are interpolated in one batched launch sequence."""
+        return SecureCirclePoly(interpolate_columns(self.intoCoordinateEvals(), twiddles))
+
+    into_coordinate_evals, interpolate_with_twiddles = intoCoordinateEvals, interpolateWithTwiddles
+
+
+class SecureCirclePoly:
+    """SecureCirclePoly<HipBackend> (poly/circle/secure_poly.ts:11-44): a QM31 polynomial as 4 coordinate CirclePolys."""
+
+    def __init__(self, polys):
+        polys = list(polys)
+        if len(polys) != 4:
+            raise ValueError("SecureCirclePoly needs 4 coordinate polynomials")
+        self.polys = polys
+
+    def __iter__(self): return iter(self.polys)
+    def __getitem__(self, i): return self.polys[i]
+    def __len__(self): return 4
+    def logSize(self) -> int: return self.polys[0].logSize()
+    log_size = logSize
+    def intoCoordinatePolys(self) -> list: return self.polys
+    into_coordinate_polys = intoCoordinatePolys
+
+    def evalColumnsAtPoint(self, point) -> list:
+        """secure_poly.ts:20-22 — one batched launch for the 4 coordinates."""
+        return HipCirclePoly.eval_at_point_batch(self.polys, point)
+
+    def evalAtPoint(self, point, ts_compat: bool = False) -> QM31:
+        """Rust: from_partial_evals of the coordinate evaluations.  The TS port returns coordinate 0 only
+        (secure_poly.ts:14-18): ts_compat=True reproduces that."""
+        cols = self.evalColumnsAtPoint(point)
+        return cols[0] if ts_compat else QM31.from_partial_evals(cols)
+
+    eval_at_point, eval_columns_at_point = evalAtPoint, evalColumnsAtPoint
+
+    def evaluateWithTwiddles(self, domain: CircleDomain, twiddles) -> SecureEvaluation:
+        """secure_poly.ts:28-39."""
+        evs = evaluate_polynomials(self.polys, domain, twiddles)
+        return SecureEvaluation(domain, SecureColumnByCoords([e.values for e in evs]))
+
+    evaluate_with_twiddles = evaluateWithTwiddles
+
+
+def domain_line_twiddles_from_tree(domain, twiddle_buffer: HipColumn) -> list:
+    """domainLineTwiddlesFromTree (poly/utils.ts:78-100): the per-layer slices of a twiddle tree for a CircleDomain or
+    LineDomain, largest layer first, as (word_offset, length) views into the device buffer — nothing is copied."""
+    log = domain.halfCoset.log_size if isinstance(domain, CircleDomain) else domain.logSize()
+    total = twiddle_buffer.len()
+    if (1 << log) > total:
+        raise ValueError("Not enough twiddles!")
+    out = []
+    for i in range(log):
+        ln = 1 << i
+        out.insert(0, (total - 2 * ln, ln))
+    return out
+
+
+domainLineTwiddlesFromTree = domain_line_twiddles_from_tree
 
 
 class LineEvaluation:
