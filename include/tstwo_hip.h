@@ -101,6 +101,12 @@ int tstwo_cfft_evaluate(uint32_t *const *cols, size_t n_cols, uint32_t log_size,
                         const uint32_t *tw, uint32_t tw_log);
 int tstwo_cfft_interpolate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,
                            const uint32_t *itw, uint32_t tw_log);
+/* CirclePoly.extend + evaluate (backend/cpu/circle.ts:71-134; pcs/prover.ts Rust text "Extension": evaluate_polynomials
+ * on the blown-up domain) without materialising the zero padding: polys[i] = 2^log_poly coefficients (read only),
+ * out[i] = 2^log_size evaluations.  Bit-identical to tstwo_poly_extend followed by tstwo_cfft_evaluate.
+ * log_size < log_poly -> TSTWO_ERR_LOG_SIZE ("log size too small"). */
+int tstwo_cfft_evaluate_extended(const uint32_t *const *polys, uint32_t log_poly, uint32_t *const *out, size_t n_cols,
+                                 uint32_t log_size, uint32_t half_initial, const uint32_t *tw, uint32_t tw_log);
 /* PolyOps.extend (circle.ts:71-82): dst[0..2^log_dst) = src[0..2^log_src) zero-padded.
  * log_dst < log_src -> TSTWO_ERR_LOG_SIZE ("log size too small"). */
 int tstwo_poly_extend(const uint32_t *src, uint32_t log_src, uint32_t *dst, uint32_t log_dst);

@@ -440,3 +440,43 @@ def test_quotients_vs_oracle(log, golden):
     exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (1, 2, 3, 4), batches)
     for k in range(4):
         assert (got[k] == exp[k]).all()
+
+
+@pytest.mark.parametrize("log_poly,log_size", [(11, 13), (12, 13), (13, 15), (14, 15), (16, 18), (17, 18), (18, 20), (20, 22), (21, 22),
+                                               (22, 24), (10, 13), (13, 13), (5, 7), (9, 12)])
+def test_cfft_evaluate_extended_matches_extend_then_evaluate(log_poly, log_size):
+    """tstwo_cfft_evaluate_extended == tstwo_poly_extend + tstwo_cfft_evaluate bit for bit (fused 1- and 2-bit extensions on
+    the tiled path, fallback elsewhere), and == the oracle at the sizes it finishes quickly."""
+    n_cols = 3 if log_size <= 20 else 2
+    half = 1 << (31 - (log_size + 1))
+    tw = L.DeviceBuffer(4 << (log_size - 1))
+    L.call("tstwo_twiddles_build", half, log_size - 1, vp(tw), vp(None))
+    polys = [rand_column(21000 + 7 * log_size + c, 1 << log_poly) for c in range(n_cols)]
+    src = [dev(p) for p in polys]
+    ref = [L.DeviceBuffer(4 << log_size) for _ in polys]
+    for s_, r in zip(src, ref):
+        L.call("tstwo_poly_extend", vp(s_), log_poly, vp(r), log_size)
+    L.call("tstwo_cfft_evaluate", L.ptr_array([r.ptr for r in ref]), n_cols, log_size, half, vp(tw), log_size - 1)
+    out = [L.DeviceBuffer(4 << log_size) for _ in polys]
+    for o in out:
+        L.call("tstwo_zero", vp(o), 4 << log_size)
+    L.call("tstwo_cfft_evaluate_extended", L.ptr_array([s_.ptr for s_ in src]), log_poly, L.ptr_array([o.ptr for o in out]), n_cols,
+           log_size, half, vp(tw), log_size - 1)
+    for o, r, s_, p in zip(out, ref, src, polys):
+        assert (o.download() == r.download()).all()
+        assert (s_.download() == p).all()                       # the polynomial is read-only
+    if log_size <= 18:
+        otw, _ = orc.precompute_twiddles(half, log_size - 1, inverse=False)
+        ext = np.concatenate([polys[0], np.zeros((1 << log_size) - polys[0].size, dtype=np.uint32)])
+        assert (out[0].download() == orc.cfft_evaluate(ext, log_size, half, otw, log_size - 1)).all()
+
+
+def test_cfft_evaluate_extended_errors():
+    tw = L.DeviceBuffer(4 << 12)
+    L.call("tstwo_twiddles_build", 1 << (31 - 14), 12, vp(tw), vp(None))
+    a, b = L.DeviceBuffer(4 << 13), L.DeviceBuffer(4 << 12)
+    with pytest.raises(L.TstwoError, match="log size too small"):
+        L.call("tstwo_cfft_evaluate_extended", L.ptr_array([a.ptr]), 13, L.ptr_array([b.ptr]), 1, 12, 1 << 18, vp(tw), 12)
+    c = L.DeviceBuffer(4 << 15)
+    with pytest.raises(L.TstwoError, match="Not enough twiddles!"):
+        L.call("tstwo_cfft_evaluate_extended", L.ptr_array([a.ptr]), 13, L.ptr_array([c.ptr]), 1, 15, 1 << 15, vp(tw), 12)

@@ -387,7 +387,43 @@ template <bool INV, int K>
 int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, u32 scale) {
     const size_t tiles = (size_t)1 << (n - 14);
     return launch_fast_kernel(fast::k_cfft_a<INV, K>, 1024, ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols,
-                              n, lo, tw_end, scale);
+                              n, lo, tw_end, scale, fast::NoSrc{});
+}
+
+// First forward pass of an evaluation whose input is a smaller polynomial (log size n - EXT) in its own buffers.
+template <int K, int EXT>
+int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, u32 lo, const u32 *tw_end) {
+    Context &c = ctx();
+    const size_t tiles = (size_t)1 << (n - 14);
+    const size_t lds_bytes = ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32);
+    auto kernel = fast::k_cfft_a<false, K, EXT>;
+    TSTWO_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
+        size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+        ColPtrs cp, sp;
+        for (size_t i = 0; i < cnt; i++) { cp.p[i] = cols[b0 + i]; sp.p[i] = const_cast<u32 *>(src[b0 + i]); }
+        const u32 cpw = pick_cols_per_wg(tiles, cnt);
+        size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
+        if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(1024), lds_bytes, c.stream, cp, (u32)cnt, cpw, n, lo, tw_end, 0u, sp);
+    }
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+template <int EXT>
+int launch_a_ext_k(u32 k, u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, u32 lo, const u32 *tw_end) {
+    switch (k) {
+        case 2: return launch_a_ext<2, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 3: return launch_a_ext<3, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 4: return launch_a_ext<4, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 5: return launch_a_ext<5, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 6: return launch_a_ext<6, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 7: return launch_a_ext<7, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 8: return launch_a_ext<8, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 9: return launch_a_ext<9, EXT>(cols, src, n_cols, n, lo, tw_end);
+        case 10: return launch_a_ext<10, EXT>(cols, src, n_cols, n, lo, tw_end);
+        default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+    }
 }
 
 template <bool INV>
@@ -503,6 +539,47 @@ int tstwo_cfft_evaluate(u32 *const *cols, size_t n_cols, u32 log_size, u32 half_
 }
 int tstwo_cfft_interpolate(u32 *const *cols, size_t n_cols, u32 log_size, u32 half_initial, const u32 *itw, u32 tw_log) {
     return cfft<true>(cols, n_cols, log_size, half_initial, itw, tw_log);
+}
+
+// CirclePoly.extend + evaluate (backend/cpu/circle.ts:71-134) in one call: polys[i] holds 2^log_poly coefficients,
+// out[i] receives the 2^log_size evaluations.  When the extension is by 1 or 2 bits and the transform takes the tiled
+// path, the zero padding is never materialised: the first pass reads the small polynomial and skips the replicating
+// layers.  Otherwise: tstwo_poly_extend into out[i], then the in-place transform.
+int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *const *out, size_t n_cols, u32 log_size, u32 half_initial,
+                                 const u32 *tw, u32 tw_log) {
+    TSTWO_REQUIRE_READY();
+    if (n_cols == 0) return TSTWO_OK;
+    if (!polys || !out) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
+    if (log_size < log_poly) return set_error(TSTWO_ERR_LOG_SIZE, "log size too small");
+    if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
+    const u32 ext = log_size - log_poly;
+    Pass passes[8];
+    int np = 0;
+    const bool tiled = log_size >= kMaxLogTileB && log_size <= 28 && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
+                       !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_FUSED_EXTEND");
+    if (tiled) np = plan_passes(log_size, passes);
+    if (tiled && np >= 2 && (ext == 1 || ext == 2) && passes[np - 1].k >= 2) {
+        if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
+        if (tw_log > 31 || ((size_t)1 << (log_size - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+        for (size_t i = 0; i < n_cols; i++)
+            if ((((uintptr_t)out[i]) & 15) || (((uintptr_t)polys[i]) & 15)) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
+        if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
+        const u32 *tw_end = tw + ((size_t)1 << tw_log);
+        const Pass &top = passes[np - 1];
+        int rc = ext == 1 ? launch_a_ext_k<1>(top.k, out, polys, n_cols, log_size, top.lo, tw_end)
+                          : launch_a_ext_k<2>(top.k, out, polys, n_cols, log_size, top.lo, tw_end);
+        if (rc) return rc;
+        for (int s = np - 2; s >= 0; s--) {
+            rc = launch_fast<false>(out, n_cols, log_size, passes[s], tw_end, 0);
+            if (rc) return rc;
+        }
+        return TSTWO_OK;
+    }
+    for (size_t i = 0; i < n_cols; i++) {
+        int rc = tstwo_poly_extend(polys[i], log_poly, out[i], log_size);
+        if (rc) return rc;
+    }
+    return cfft<false>(out, n_cols, log_size, half_initial, tw, tw_log);
 }
 
 }  // extern "C"

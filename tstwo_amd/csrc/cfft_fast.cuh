@@ -224,9 +224,18 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
 
 // ------------------------------------------------------------------------------------------------
 // Strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^C words (C = 14 - K), 1024 lanes.
-template <bool INV, int K>
+// EXT > 0 (forward only, the pass that holds the transform's top layers): the input is a polynomial of log size
+// n - EXT in its own buffers (`src`), zero-extended to log size n on the fly.  The top EXT layers of a zero-padded input
+// only replicate (butterfly(a, 0, t) = (a, a)), so the quarter-tile vectors a lane needs are copies of each other:
+// they are loaded once from the small polynomial, the replicated layers are skipped, and the result goes to `cols`.
+struct NoSrc {};
+template <int EXT> struct SrcTable { using type = ColPtrs; };
+template <> struct SrcTable<0> { using type = NoSrc; };
+
+template <bool INV, int K, int EXT = 0>
 __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n, u32 lo,
-                                                const u32 *__restrict__ tw_end, u32 scale) {
+                                                const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<EXT>::type src) {
+    static_assert(EXT == 0 || (!INV && K >= 2 && EXT <= 2), "fused extension: forward pass with two register layers");
     constexpr int LOGT = 14, THREADS = 1024, C = LOGT - K;
     constexpr u32 T = 1u << LOGT, QT = T / 4;
     constexpr int F = K >= 2 ? 2 : 1;          // layers fused into the load / store
@@ -278,17 +287,40 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
     if constexpr (!INV || R == 0) {
         // forward (and the LDS-free case): four quarter-tile vectors per lane
         uint4 pf[4];
-        {
-            const u32 *__restrict__ d = cols.p[col0] + base;
+        // loads of the lane's four quarter-tile vectors (j = 2 * top bit + second bit); with EXT the vectors that differ
+        // only in replicated bits are one load from the small polynomial
+        auto load_tile = [&](const u32 *__restrict__ d) {
+            if constexpr (EXT == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(d + goff(4 * t + j * QT));
-        }
+                for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(d + goff(4 * t + j * QT));
+            } else if constexpr (EXT == 1) {
+                pf[0] = *reinterpret_cast<const uint4 *>(d + goff(4 * t));
+                pf[1] = *reinterpret_cast<const uint4 *>(d + goff(4 * t + QT));
+            } else {
+                pf[0] = *reinterpret_cast<const uint4 *>(d + goff(4 * t));
+            }
+        };
+        auto src_of = [&](u32 col) -> const u32 * {
+            if constexpr (EXT == 0) return cols.p[col] + base;
+            else return src.p[col] + base;       // the first pass has hi == 0: base only carries bits below the replicated ones
+        };
+        load_tile(src_of(col0));
         for (u32 col = col0; col < col1; col++) {
             u32 *__restrict__ data = cols.p[col] + base;
-            const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+            const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
             u32 tt = t;
             asm volatile("" : "+v"(tt));     // opaque per iteration: keeps the 16 scatter addresses out of loop-invariant registers
-            top_layers<INV, F == 2>(pf, ta, tb0, tb1);
+            if constexpr (EXT == 0) {
+                top_layers<INV, F == 2>(pf, ta, tb0, tb1);
+            } else if constexpr (EXT == 1) {     // top layer replicates: x2 = x0, x3 = x1; second layer is real
+                pf[2] = pf[0]; pf[3] = pf[1];
+                u32 *p0 = reinterpret_cast<u32 *>(&pf[0]), *p1 = reinterpret_cast<u32 *>(&pf[1]);
+                u32 *p2 = reinterpret_cast<u32 *>(&pf[2]), *p3 = reinterpret_cast<u32 *>(&pf[3]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { bfly<false>(p0[k], p1[k], tb0); bfly<false>(p2[k], p3[k], tb1); }
+            } else {                              // both register layers replicate
+                pf[1] = pf[0]; pf[2] = pf[0]; pf[3] = pf[0];
+            }
             if constexpr (R == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -296,8 +328,7 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
                     if (INV && scale) x = scale4(x, scale);
                     *reinterpret_cast<uint4 *>(data + goff(4 * t + j * QT)) = x;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + goff(4 * t + j * QT));
+                load_tile(next);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -305,8 +336,7 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
                     p[0] = pf[j].x; p[1] = pf[j].y; p[2] = pf[j].z; p[3] = pf[j].w;
                 }
                 lds_barrier();
-#pragma unroll
-                for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + goff(4 * t + j * QT));
+                load_tile(next);
                 if constexpr (G1 > 0) {
                     lds_stage<G1, C + 4, LOGT, THREADS, false>(lds, twl);
                     lds_barrier();

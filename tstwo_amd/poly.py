@@ -137,13 +137,20 @@ def evaluate_polynomials(polys, domain: CircleDomain, twiddles: TwiddleTree) -> 
     """PolyOps.evaluatePolynomials (poly/circle/ops.ts:89-101), batched: one launch sequence for all columns."""
     _check_tree(domain, twiddles)
     n = domain.log_size()
-    outs = []
+    polys = list(polys)
     for p in polys:
         if n < p.logSize():
             raise ValueError("log size too small")
-        outs.append(HipCirclePoly.extend_static(p, n).coeffs)
-    L.call("tstwo_cfft_evaluate", L.ptr_array([c.ptr for c in outs]), len(outs), n, domain.halfCoset.initial_index.value,
-           _vp(twiddles.twiddles.ptr), twiddles.log_size)
+    outs = [HipColumn.uninitialized(1 << n) for _ in polys]
+    # extend + evaluate per group of equal-sized polynomials (tstwo_cfft_evaluate_extended never materialises the zero
+    # padding when the extension is 1-2 bits); same-size groups share one launch sequence
+    by_log = {}
+    for i, p in enumerate(polys):
+        by_log.setdefault(p.logSize(), []).append(i)
+    for lg, idxs in by_log.items():
+        L.call("tstwo_cfft_evaluate_extended", L.ptr_array([polys[i].coeffs.ptr for i in idxs]), lg,
+               L.ptr_array([outs[i].ptr for i in idxs]), len(idxs), n, domain.halfCoset.initial_index.value,
+               _vp(twiddles.twiddles.ptr), twiddles.log_size)
     if HipCirclePoly.compatLog3Swap and n == 3:
         for c in outs:
             _swap57(c)
