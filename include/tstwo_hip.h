@@ -101,6 +101,11 @@ int tstwo_cfft_evaluate(uint32_t *const *cols, size_t n_cols, uint32_t log_size,
                         const uint32_t *tw, uint32_t tw_log);
 int tstwo_cfft_interpolate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,
                            const uint32_t *itw, uint32_t tw_log);
+/* Out-of-place interpolate: src[i] (evaluations, read only) -> dst[i] (coefficients).  The reference's interpolate has
+ * value semantics (the evaluation survives, backend/cpu/circle.ts:136-207 works on a copy); here the copy is folded into
+ * the first pass.  Bit-identical to copying and calling tstwo_cfft_interpolate. */
+int tstwo_cfft_interpolate_to(const uint32_t *const *src, uint32_t *const *dst, size_t n_cols, uint32_t log_size,
+                              uint32_t half_initial, const uint32_t *itw, uint32_t tw_log);
 /* CirclePoly.extend + evaluate (backend/cpu/circle.ts:71-134; pcs/prover.ts Rust text "Extension": evaluate_polynomials
  * on the blown-up domain) without materialising the zero padding: polys[i] = 2^log_poly coefficients (read only),
  * out[i] = 2^log_size evaluations.  Bit-identical to tstwo_poly_extend followed by tstwo_cfft_evaluate.

@@ -866,3 +866,19 @@ def test_row_shard_rejects_misaligned():
     with pytest.raises(L.TstwoError, match="4-aligned"):
         L.call("tstwo_fri_fold_line_rows", sh.ptrs(), n - 1, 2, 6, C.c_void_p(tw.itwiddles.ptr), tw.log_size,
                L.u32x([1, 0, 0, 0]), T.SecureColumnByCoords.zeros(6).ptrs())
+
+
+def test_interpolate_columns_mixed_domains():
+    """poly/circle/ops.ts:73-82: interpolateColumns interpolates each column on its own domain.  Regression: columns of
+    different sizes in one call used to be transformed with the first column's size (writing past the smaller buffers)."""
+    tw = T.precompute_twiddles(T.CanonicCoset(9).circleDomain().halfCoset)
+    logs = [8, 6, 9, 6, 8]
+    cols = [rand_column(17000 + i, 1 << lg) for i, lg in enumerate(logs)]
+    evs = [T.HipCircleEvaluation(T.CanonicCoset(lg).circleDomain(), c) for lg, c in zip(logs, cols)]
+    polys = T.interpolate_columns(evs, tw)
+    assert [p.logSize() for p in polys] == logs
+    for p, e, c, lg in zip(polys, evs, cols, logs):
+        assert (e.values.to_numpy() == c).all()                                  # evaluations survive
+        h = T.CanonicCoset(lg).circleDomain().halfCoset.initial_index.value
+        _, oitw = orc.precompute_twiddles(h, lg - 1)
+        assert (p.coeffs.to_numpy() == orc.cfft_interpolate(c, lg, h, oitw, lg - 1)).all()

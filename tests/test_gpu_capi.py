@@ -480,3 +480,24 @@ def test_cfft_evaluate_extended_errors():
     c = L.DeviceBuffer(4 << 15)
     with pytest.raises(L.TstwoError, match="Not enough twiddles!"):
         L.call("tstwo_cfft_evaluate_extended", L.ptr_array([a.ptr]), 13, L.ptr_array([c.ptr]), 1, 15, 1 << 15, vp(tw), 12)
+
+
+@pytest.mark.parametrize("n", [3, 8, 12, 13, 14, 16, 19, 22, 23])
+def test_cfft_interpolate_to_matches_in_place(n):
+    """tstwo_cfft_interpolate_to (source untouched, copy folded into the first pass) == copy + tstwo_cfft_interpolate."""
+    n_cols = 3 if n <= 20 else 2
+    half = 1 << (31 - (n + 1))
+    tw, itw = L.DeviceBuffer(4 << (n - 1)), L.DeviceBuffer(4 << (n - 1))
+    L.call("tstwo_twiddles_build", half, n - 1, vp(tw), vp(itw))
+    evals = [rand_column(22000 + 5 * n + c, 1 << n) for c in range(n_cols)]
+    src = [dev(e) for e in evals]
+    ref = [dev(e) for e in evals]
+    L.call("tstwo_cfft_interpolate", ptrs(ref), n_cols, n, half, vp(itw), n - 1)
+    dst = [L.DeviceBuffer(4 << n) for _ in evals]
+    L.call("tstwo_cfft_interpolate_to", ptrs(src), ptrs(dst), n_cols, n, half, vp(itw), n - 1)
+    for d, r, s_, e in zip(dst, ref, src, evals):
+        assert (d.download() == r.download()).all()
+        assert (s_.download() == e).all()
+    # and evaluating the coefficients gives the evaluations back
+    L.call("tstwo_cfft_evaluate", ptrs(dst), n_cols, n, half, vp(tw), n - 1)
+    assert (dst[0].download() == evals[0]).all()

@@ -432,9 +432,9 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         const size_t tiles = (size_t)1 << (n - ps.k);
         const size_t lds = (((size_t)1 << ps.k) + ((size_t)1 << (ps.k - 5)) + ((size_t)1 << (ps.k - 4))) * sizeof(u32);
         switch (ps.k) {
-            case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale);
-            case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale);
-            case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale);
+            case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale, fast::NoSrc{});
+            case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale, fast::NoSrc{});
+            case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale, fast::NoSrc{});
             default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported bottom pass");
         }
     }
@@ -539,6 +539,57 @@ int tstwo_cfft_evaluate(u32 *const *cols, size_t n_cols, u32 log_size, u32 half_
 }
 int tstwo_cfft_interpolate(u32 *const *cols, size_t n_cols, u32 log_size, u32 half_initial, const u32 *itw, u32 tw_log) {
     return cfft<true>(cols, n_cols, log_size, half_initial, itw, tw_log);
+}
+
+// Out-of-place interpolation: src[i] (evaluations, left untouched) -> dst[i] (coefficients).  On the tiled path the first
+// (bottom) pass reads src and writes dst, so the clone the value-semantics API needs costs no extra pass over HBM.
+int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_cols, u32 log_size, u32 half_initial, const u32 *itw, u32 tw_log) {
+    TSTWO_REQUIRE_READY();
+    if (n_cols == 0) return TSTWO_OK;
+    if (!src || !dst) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
+    if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
+    const bool tiled = log_size >= kMaxLogTileB && log_size <= 28 && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
+                       !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_OOP");
+    if (tiled) {
+        if (!itw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
+        if (tw_log > 31 || ((size_t)1 << (log_size - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+        for (size_t i = 0; i < n_cols; i++)
+            if ((((uintptr_t)dst[i]) & 15) || (((uintptr_t)src[i]) & 15)) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
+        if (((uintptr_t)itw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
+        Context &c = ctx();
+        Pass passes[8];
+        const int np = plan_passes(log_size, passes);
+        const u32 *tw_end = itw + ((size_t)1 << tw_log);
+        const u32 n_inv = host::inv((1u << log_size) % M31_P);
+        // bottom pass, out of place
+        {
+            const size_t tiles = (size_t)1 << (log_size - 13);
+            const size_t lds = (((size_t)1 << 13) + ((size_t)1 << 8) + ((size_t)1 << 9)) * sizeof(u32);
+            auto kernel = fast::k_cfft_b<true, 13, true>;
+            TSTWO_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
+                size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+                ColPtrs cp, sp;
+                for (size_t i = 0; i < cnt; i++) { cp.p[i] = dst[b0 + i]; sp.p[i] = const_cast<u32 *>(src[b0 + i]); }
+                const u32 cpw = pick_cols_per_wg(tiles, cnt);
+                size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
+                if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
+                hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), lds, c.stream, cp, (u32)cnt, cpw, log_size, tw_end,
+                                   np == 1 ? n_inv : 0u, sp);
+            }
+            TSTWO_LAUNCH_CHECK();
+        }
+        for (int s = 1; s < np; s++) {
+            int rc = launch_fast<true>(dst, n_cols, log_size, passes[s], tw_end, s == np - 1 ? n_inv : 0u);
+            if (rc) return rc;
+        }
+        return TSTWO_OK;
+    }
+    for (size_t i = 0; i < n_cols; i++) {
+        int rc = tstwo_copy(dst[i], src[i], (size_t)4 << log_size);
+        if (rc) return rc;
+    }
+    return cfft<true>(dst, n_cols, log_size, half_initial, itw, tw_log);
 }
 
 // CirclePoly.extend + evaluate (backend/cpu/circle.ts:71-134) in one call: polys[i] holds 2^log_poly coefficients,

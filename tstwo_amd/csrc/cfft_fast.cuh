@@ -94,12 +94,18 @@ __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
     return make_uint4(m31_mul(x.x, s), m31_mul(x.y, s), m31_mul(x.z, s), m31_mul(x.w, s));
 }
 
+// optional second pointer table of a kernel (a read-only source); an empty struct when the kernel works in place
+struct NoSrc {};
+template <int EXT> struct SrcTable { using type = ColPtrs; };
+template <> struct SrcTable<0> { using type = NoSrc; };
+
 // ------------------------------------------------------------------------------------------------
 // Bottom pass: layers 0..LOGT-1 (circle layer included) of a contiguous 2^LOGT-word tile, LOGT in 11..13
 // (2^(LOGT-4) lanes).  LOGT = 13 is the default; smaller tiles give more workgroups when there are few columns.
-template <bool INV, int LOGT>
+// OOP: tiles are read from `src` (left untouched) and written to `cols` — the first pass of an out-of-place interpolation.
+template <bool INV, int LOGT, bool OOP = false>
 __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
-                                                 const u32 *__restrict__ tw_end, u32 scale) {
+                                                 const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<OOP ? 1 : 0>::type src) {
     constexpr int THREADS = 1 << (LOGT - 4);
     constexpr int GM = LOGT - 10;              // layers of the middle LDS stage (bits [8, LOGT-2))
     constexpr u32 T = 1u << LOGT, QT = T / 4;
@@ -137,16 +143,20 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
         ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
     }
 
+    auto src_of = [&](u32 col) -> const u32 * {
+        if constexpr (OOP) return src.p[col] + base;
+        else return cols.p[col] + base;
+    };
     uint4 pf[4];
     {
-        const u32 *__restrict__ d = cols.p[col0] + base;
+        const u32 *__restrict__ d = src_of(col0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
             pf[j] = *reinterpret_cast<const uint4 *>(d + (INV ? 16 * t + 4 * j : 4 * t + j * QT));
     }
     for (u32 col = col0; col < col1; col++) {
         u32 *__restrict__ data = cols.p[col] + base;
-        const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+        const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
         if (!INV) {
             top_layers<false, true>(pf, ta, tb0, tb1);                    // layers LOGT-1, LOGT-2
 #pragma unroll
@@ -228,10 +238,6 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
 // n - EXT in its own buffers (`src`), zero-extended to log size n on the fly.  The top EXT layers of a zero-padded input
 // only replicate (butterfly(a, 0, t) = (a, a)), so the quarter-tile vectors a lane needs are copies of each other:
 // they are loaded once from the small polynomial, the replicated layers are skipped, and the result goes to `cols`.
-struct NoSrc {};
-template <int EXT> struct SrcTable { using type = ColPtrs; };
-template <> struct SrcTable<0> { using type = NoSrc; };
-
 template <bool INV, int K, int EXT = 0>
 __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n, u32 lo,
                                                 const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<EXT>::type src) {

@@ -158,19 +158,30 @@ def evaluate_polynomials(polys, domain: CircleDomain, twiddles: TwiddleTree) -> 
 
 
 def interpolate_columns(evals, twiddles: TwiddleTree) -> list:
-    """PolyOps.interpolateColumns (poly/circle/ops.ts:73-82), batched over columns of one domain."""
-    if not evals:
-        return []
-    domain = evals[0].domain
-    _check_tree(domain, twiddles)
-    n = domain.log_size()
-    outs = [e.values.clone() for e in evals]
-    if HipCirclePoly.compatLog3Swap and n == 3:
-        for c in outs:
-            _swap57(c)
-    L.call("tstwo_cfft_interpolate", L.ptr_array([c.ptr for c in outs]), len(outs), n, domain.halfCoset.initial_index.value,
-           _vp(twiddles.itwiddles.ptr), twiddles.log_size)
-    return [HipCirclePoly(c) for c in outs]
+    """PolyOps.interpolateColumns (poly/circle/ops.ts:73-82): every column is interpolated on ITS OWN domain (the default
+    calls interpolateWithTwiddles per element); columns sharing a domain share one batched launch sequence."""
+    evals = list(evals)
+    outs = [None] * len(evals)
+    groups = {}
+    for i, e in enumerate(evals):
+        groups.setdefault((e.domain.log_size(), e.domain.halfCoset.initial_index.value), []).append(i)
+    for (n, initial), idxs in groups.items():
+        domain = evals[idxs[0]].domain
+        _check_tree(domain, twiddles)
+        if HipCirclePoly.compatLog3Swap and n == 3:
+            cols = [evals[i].values.clone() for i in idxs]
+            for c in cols:
+                _swap57(c)
+            L.call("tstwo_cfft_interpolate", L.ptr_array([c.ptr for c in cols]), len(cols), n, initial,
+                   _vp(twiddles.itwiddles.ptr), twiddles.log_size)
+        else:
+            # value semantics (the evaluations survive) without a separate clone: the first pass reads evals, writes cols
+            cols = [HipColumn.uninitialized(1 << n) for _ in idxs]
+            L.call("tstwo_cfft_interpolate_to", L.ptr_array([evals[i].values.ptr for i in idxs]), L.ptr_array([c.ptr for c in cols]),
+                   len(cols), n, initial, _vp(twiddles.itwiddles.ptr), twiddles.log_size)
+        for i, c in zip(idxs, cols):
+            outs[i] = HipCirclePoly(c)
+    return outs
 
 
 class HipCircleEvaluation:
