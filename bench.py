@@ -61,10 +61,17 @@ def splitmix_column(seed: int, n: int) -> np.ndarray:
     return out
 
 
+def cpu_oracle():
+    """The CPU oracle module (oracle/): reached ONLY from the cpu_baseline legs — this file's and tools/bench_configs.py's,
+    which times BASELINE configs 1-4 the same way.  Never imported by the product (tstwo_amd/)."""
+    from oracle import oracle as orc
+    return orc
+
+
 def cpu_baseline(sample_cols: int):
     """CPU oracle (oracle/, 'port') on a bounded sample: `sample_cols` of the 32 columns, same log size:
     CFFT evaluate + Merkle commit over those columns, one thread."""
-    from oracle import oracle as orc
+    orc = cpu_oracle()
     n = LOG_SIZE
     half = orc.lib().orc_half_odds_initial(n - 1)
     tw, _ = orc.precompute_twiddles(half, n - 1, inverse=False)       # untimed, like the GPU side

@@ -59,7 +59,8 @@ def cpu_time(fn, units, unit_name, sample):
 
 vp = lambda b: C.c_void_p(b.ptr)
 if not args.no_cpu:
-    from oracle import oracle as orc
+    from bench import cpu_oracle      # the cpu_baseline leg: the oracle is the timed CPU "port", never part of the GPU path
+    orc = cpu_oracle()
 
 # ---------------------------------------------------------------- config 1: M31 add / mul / batch_inverse on 2^20
 n1 = 1 << 20

@@ -97,8 +97,10 @@ class SecureColumnByCoords:
     """SoA of 4 M31 columns holding QM31 values (fields/secure_columns.ts:124-217), device resident."""
 
     def __init__(self, columns):
-        assert len(columns) == 4
-        self.columns = list(columns)
+        columns = list(columns)
+        if len(columns) != 4 or len({c.len() for c in columns}) != 1:
+            raise ValueError("SecureColumnByCoords needs 4 coordinate columns of one length")
+        self.columns = columns
 
     @staticmethod
     def zeros(n): return SecureColumnByCoords([HipColumn.zeros(n) for _ in range(4)])
