@@ -882,3 +882,67 @@ def test_interpolate_columns_mixed_domains():
         h = T.CanonicCoset(lg).circleDomain().halfCoset.initial_index.value
         _, oitw = orc.precompute_twiddles(h, lg - 1)
         assert (p.coeffs.to_numpy() == orc.cfft_interpolate(c, lg, h, oitw, lg - 1)).all()
+
+
+# ---------------------------------------------------------------- BASELINE.json full sizes (configs 3 and 4): spot checks
+def _device_rand_secure(seed, n):
+    return T.SecureColumnByCoords.from_numpy([rand_column(seed + k, n) for k in range(4)])
+
+
+def test_config4_full_size_fold_and_merkle():
+    """Config 4 at its real size (log 24 secure column): fold_circle_into_line and fold_line agree with the host
+    SparseEvaluation fold (itself checked against the oracle on CPU) at random rows; the Merkle tree over the 4 coordinate
+    columns answers random queries with a decommitment the host verifier (hashlib) accepts."""
+    from tstwo_amd.fri_verifier import SparseEvaluation
+    n = 24
+    domain = T.CanonicCoset(n).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    src = T.SecureEvaluation(domain, _device_rand_secure(18000, 1 << n))
+    alpha = T.QM31.from_u32_unchecked(19283, 1, 2, 3)
+    dst = T.LineEvaluation.new_zero(T.LineDomain(domain.halfCoset))
+    T.fold_circle_into_line(dst, src, alpha, tw)
+    rng = np.random.default_rng(24)
+    rows = sorted(int(r) for r in rng.integers(0, 1 << (n - 1), size=12))
+    pairs = src.values.gather([2 * r + k for r in rows for k in (0, 1)])
+    got = dst.values.gather(rows)
+    for j, r in enumerate(rows):
+        s = SparseEvaluation([[pairs[2 * j], pairs[2 * j + 1]]], [T.bit_reverse_index(2 * r, n)])
+        assert s.fold_circle(alpha, domain)[0].tup() == got[j].tup()
+    line = T.fold_line(dst, alpha, tw)
+    rows2 = sorted(int(r) for r in rng.integers(0, 1 << (n - 2), size=12))
+    pairs2 = dst.values.gather([2 * r + k for r in rows2 for k in (0, 1)])
+    got2 = line.values.gather(rows2)
+    for j, r in enumerate(rows2):
+        s = SparseEvaluation([[pairs2[2 * j], pairs2[2 * j + 1]]], [T.bit_reverse_index(2 * r, n - 1)])
+        assert s.fold_line(alpha, dst.domain())[0].tup() == got2[j].tup()
+    tree = T.MerkleProver.commit(src.values.columns)
+    queries = {n: sorted(set(int(q) for q in rng.integers(0, 1 << n, size=16)))}
+    values, dec = tree.decommit(queries, src.values.columns)
+    assert len(dec.hashWitness) > 16 * 10
+    T.MerkleVerifier(T.Blake2sMerkleHasher, tree.root(), [n] * 4).verify(queries, values, dec)
+
+
+def test_config3_full_size_quotients_and_inverse():
+    """Config 3 at its real size (4 columns, log 22): the device quotient column equals the host row quotients at random
+    rows; QM31 batch inverse times its input is one everywhere."""
+    n = 22
+    domain = T.CanonicCoset(n).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    polys = [T.HipCirclePoly(rand_column(19000 + c, 1 << (n - 1))) for c in range(4)]
+    evals = T.evaluate_polynomials(polys, domain, tw)
+    pt = T.SECURE_FIELD_CIRCLE_GEN
+    samples = [[T.PointSample(pt, v)] for v in T.HipCirclePoly.eval_at_point_batch(polys, pt)]
+    coeff = T.QM31.from_u32_unchecked(1, 2, 3, 4)
+    quot = T.compute_fri_quotients(evals, samples, coeff, 1)[0]
+    rng = np.random.default_rng(22)
+    queries = sorted(set(int(q) for q in rng.integers(0, 1 << n, size=10)))
+    vals = [v for q in queries for v in (e.values.at(q) for e in evals)]
+    ans = T.fri_answers([[n] * 4], [samples], coeff, {n: queries}, [vals], [{n: 4}])
+    assert [a.tup() for a in ans[0]] == [g.tup() for g in quot.values.gather(queries)]
+    # the quotient of degree-2^21 polynomials sampled at their true values is itself of low degree
+    qp = quot.interpolateWithTwiddles(tw)
+    assert all(p.isInFriSpace(n - 1) for p in qp)
+    sec = _device_rand_secure(19500, 1 << n)
+    inv = T.HipBackend().batchInverse(sec)
+    prod = T.HipBackend().secureMul(sec, inv).to_numpy()
+    assert (prod[0] == 1).all() and not prod[1].any() and not prod[2].any() and not prod[3].any()

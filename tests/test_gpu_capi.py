@@ -501,3 +501,29 @@ def test_cfft_interpolate_to_matches_in_place(n):
     # and evaluating the coefficients gives the evaluations back
     L.call("tstwo_cfft_evaluate", ptrs(dst), n_cols, n, half, vp(tw), n - 1)
     assert (dst[0].download() == evals[0]).all()
+
+
+@pytest.mark.parametrize("n", [26, 28])
+def test_cfft_maximum_sizes(n):
+    """The largest transforms the tiled path plans (3 passes at log 26, 3 at log 28; 1 GiB column at log 28): the
+    evaluation agrees with eval_at_point at sampled domain points and interpolate inverts it."""
+    tw, itw = build_twiddles(n - 1)
+    a = rand_column(n, 1 << n)
+    d = [dev(a)]
+    coeffs = dev(a)
+    L.call("tstwo_cfft_evaluate", ptrs(d), 1, n, half_odds(n - 1), vp(tw), n - 1)
+    rng = np.random.default_rng(n)
+    for i in rng.integers(0, 1 << n, size=3):
+        p = OL.orc_circle_domain_at(half_odds(n - 1), n - 1, int(i))
+        out = (C.c_uint32 * 4)()
+        L.call("tstwo_eval_at_point", vp(coeffs), n, L.u32x((p.x, 0, 0, 0)), L.u32x((p.y, 0, 0, 0)), out)
+        got = d[0].download(np.uint32, 1, 4 * OL.orc_bit_reverse_index(int(i), n))
+        assert tuple(out) == (int(got[0]), 0, 0, 0)
+    if n == 26:                                                        # one point through the CPU oracle as well
+        i = int(rng.integers(0, 1 << n))
+        p = OL.orc_circle_domain_at(half_odds(n - 1), n - 1, i)
+        v = orc.eval_at_point(a, n, (p.x, 0, 0, 0), (p.y, 0, 0, 0))
+        assert v == (int(d[0].download(np.uint32, 1, 4 * OL.orc_bit_reverse_index(i, n))[0]), 0, 0, 0)
+    L.call("tstwo_cfft_interpolate", ptrs(d), 1, n, half_odds(n - 1), vp(itw), n - 1)
+    back = host(d[0], 1 << n)
+    assert (back == a).all()
