@@ -527,3 +527,9 @@ def test_cfft_maximum_sizes(n):
     L.call("tstwo_cfft_interpolate", ptrs(d), 1, n, half_odds(n - 1), vp(itw), n - 1)
     back = host(d[0], 1 << n)
     assert (back == a).all()
+
+
+def test_cfft_rejects_sizes_above_28():
+    d = dev(rand_column(1, 16))
+    with pytest.raises(L.TstwoError, match="log_size > 28 is not supported"):
+        L.call("tstwo_cfft_evaluate", ptrs([d]), 1, 29, 1, vp(d), 28)

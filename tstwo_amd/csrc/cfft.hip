@@ -457,6 +457,7 @@ template <bool INV>
 int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw, u32 tw_log) {
     TSTWO_REQUIRE_READY();
     if (n == 0 || n > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
+    if (n > 28) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size > 28 is not supported (1 GiB per column is the largest tested transform)");
     if (n_cols == 0) return TSTWO_OK;
     if (!cols) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
     Context &c = ctx();
