@@ -114,25 +114,38 @@ export class HipCirclePoly extends CirclePoly<HipBackend> {
     return new HipCirclePoly(out);
   }
   static evaluate(poly: HipCirclePoly, domain: CircleDomain, tw: TwiddleTree<HipBackend, HipColumn>): HipCircleEvaluation {
-    checkTree(domain, tw);
-    const n = domain.log_size();
-    const col = HipCirclePoly.extend(poly, n).dev;
-    check(hip.tstwo_cfft_evaluate(ptr(ptrs([col.dev])), 1n, n, domain.halfCoset.initial_index.value, tw.twiddles.dev, tw.rootCoset.log_size));
-    return new HipCircleEvaluation(domain, col);
+    return HipCirclePoly.evaluatePolynomials([poly], domain, tw)[0]!;
   }
+  /** Value semantics (the evaluation survives) with the copy folded into the first pass (tstwo_cfft_interpolate_to). */
   static interpolate(ev: HipCircleEvaluation, tw: TwiddleTree<HipBackend, HipColumn>): HipCirclePoly {
     checkTree(ev.domain, tw);
-    const col = ev.dev.clone();
-    check(hip.tstwo_cfft_interpolate(ptr(ptrs([col.dev])), 1n, ev.domain.log_size(), ev.domain.halfCoset.initial_index.value, tw.itwiddles.dev, tw.rootCoset.log_size));
+    const n = ev.domain.log_size();
+    const col = HipColumn.uninitialized(1 << n);
+    check(hip.tstwo_cfft_interpolate_to(ptr(ptrs([ev.dev.dev])), ptr(ptrs([col.dev])), 1n, n, ev.domain.halfCoset.initial_index.value, tw.itwiddles.dev, tw.rootCoset.log_size));
     return new HipCirclePoly(col);
   }
-  /** PolyOps.evaluatePolynomials, batched: one launch sequence for all columns of a domain (poly/circle/ops.ts:89-101). */
+  /** PolyOps.evaluatePolynomials, batched (poly/circle/ops.ts:89-101): extend + evaluate per group of equal-sized polynomials
+   *  without materialising the zero padding (tstwo_cfft_evaluate_extended). */
   static evaluatePolynomials(polys: HipCirclePoly[], domain: CircleDomain, tw: TwiddleTree<HipBackend, HipColumn>): HipCircleEvaluation[] {
     checkTree(domain, tw);
     const n = domain.log_size();
-    const cols = polys.map((p) => HipCirclePoly.extend(p, n).dev);
-    check(hip.tstwo_cfft_evaluate(ptr(ptrs(cols.map((c) => c.dev))), BigInt(cols.length), n, domain.halfCoset.initial_index.value, tw.twiddles.dev, tw.rootCoset.log_size));
-    return cols.map((c) => new HipCircleEvaluation(domain, c));
+    const outs = polys.map((p) => {
+      if (n < p.logSize()) throw new Error("log size too small");
+      return HipColumn.uninitialized(1 << n);
+    });
+    const byLog = new Map<number, number[]>();
+    polys.forEach((p, i) => byLog.set(p.logSize(), [...(byLog.get(p.logSize()) ?? []), i]));
+    for (const [lg, idxs] of byLog) {
+      check(hip.tstwo_cfft_evaluate_extended(ptr(ptrs(idxs.map((i) => polys[i]!.dev.dev))), lg, ptr(ptrs(idxs.map((i) => outs[i]!.dev))),
+        BigInt(idxs.length), n, domain.halfCoset.initial_index.value, tw.twiddles.dev, tw.rootCoset.log_size));
+    }
+    return outs.map((c) => new HipCircleEvaluation(domain, c));
+  }
+  /** All polynomials of one size at one point in one launch sequence (prove_values' out-of-domain sampling). */
+  static evalAtPointBatch(polys: HipCirclePoly[], point: CirclePoint<QM31>): QM31[] {
+    const out = new Uint32Array(4 * polys.length);
+    check(hip.tstwo_eval_at_point_batch(ptr(ptrs(polys.map((p) => p.dev.dev))), BigInt(polys.length), polys[0]!.logSize(), ptr(q4(point.x)), ptr(q4(point.y)), ptr(out)));
+    return polys.map((_, i) => QM31.from_u32_unchecked(out[4 * i]!, out[4 * i + 1]!, out[4 * i + 2]!, out[4 * i + 3]!));
   }
   static eval_at_point(poly: HipCirclePoly, point: CirclePoint<QM31>): QM31 {
     const out = new Uint32Array(4);
@@ -188,5 +201,28 @@ export class HipMerkleOps {
     const layers = new DeviceBuffer(32 * ((2 << maxLog) - 1)), root = new Uint8Array(32);
     check(hip.tstwo_merkle_commit(ptr(ptrs(columns.map((c) => c.dev))), ptr(u32s(logs)), BigInt(columns.length), layers.dev, ptr(root)));
     return { layers, root };
+  }
+  /** MerkleProver.decommit (vcs/prover.ts:32-109) on a tree built by commit(): the walk and both gathers run in the library. */
+  decommit(layers: DeviceBuffer, columns: readonly HipColumn[], queriesPerLogSize: Map<number, number[]>):
+      { queriedValues: M31[]; hashWitness: Uint8Array[]; columnWitness: M31[] } {
+    const logs = columns.map((c) => Math.log2(c.len()));
+    const maxLog = columns.length ? Math.max(...logs) : 0;
+    const sets = [...queriesPerLogSize].filter(([, q]) => q.length > 0);
+    const totalQ = sets.reduce((a, [, q]) => a + q.length, 0);
+    const capV = Math.max(1, totalQ * Math.max(1, columns.length)), capH = Math.max(1, 2 * totalQ * (maxLog + 1));
+    const qArrays = sets.map(([, q]) => BigUint64Array.from(q.map(BigInt)));
+    const qPtrs = BigUint64Array.from(qArrays.map((a) => BigInt(ptr(a))));
+    const nQ = BigUint64Array.from(sets.map(([, q]) => BigInt(q.length)));
+    const queried = new Uint32Array(capV), colWit = new Uint32Array(capV), hashes = new Uint8Array(32 * capH);
+    const counts = BigUint64Array.from([BigInt(capV), BigInt(capH), BigInt(capV)]);
+    check(hip.tstwo_merkle_decommit(layers.dev, maxLog, ptr(ptrs(columns.map((c) => c.dev))), ptr(u32s(logs)), BigInt(columns.length),
+      ptr(u32s(sets.map(([lg]) => lg))), ptr(qPtrs), ptr(nQ), BigInt(sets.length),
+      ptr(queried), ptr(counts.subarray(0, 1)), ptr(hashes), ptr(counts.subarray(1, 2)), ptr(colWit), ptr(counts.subarray(2, 3))));
+    const [nq, nh, nw] = [Number(counts[0]), Number(counts[1]), Number(counts[2])];
+    return {
+      queriedValues: Array.from(queried.subarray(0, nq), (v) => M31.from_u32_unchecked(v)),
+      hashWitness: Array.from({ length: nh }, (_, i) => hashes.slice(32 * i, 32 * i + 32)),
+      columnWitness: Array.from(colWit.subarray(0, nw), (v) => M31.from_u32_unchecked(v)),
+    };
   }
 }
