@@ -68,9 +68,15 @@ def cpu_oracle():
     return orc
 
 
-def cpu_baseline(sample_cols: int):
-    """CPU oracle (oracle/, 'port') on a bounded sample: `sample_cols` of the 32 columns, same log size:
-    CFFT evaluate + Merkle commit over those columns, one thread."""
+def cpu_baseline(sample_cols: int, threads: int = 0):
+    """CPU oracle (oracle/, 'port') timed beside the GPU step, two legs on a bounded sample:
+      * one thread: `sample_cols` of the 32 columns — CFFT evaluate + Merkle commit over them;
+      * all cores (reported as cpu_baseline.value): the full 32-column step, column-parallel CFFT (one column per task)
+        and a row-sharded Merkle tree (each thread hashes a contiguous leaf range to a subtree root; the top levels are
+        combined with hashlib) on `threads` threads (default: min(cores, 32), a power of two).  ctypes releases the GIL.
+    Both are the same scalar C code; nothing here is on the GPU path."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     orc = cpu_oracle()
     n = LOG_SIZE
     half = orc.lib().orc_half_odds_initial(n - 1)
@@ -81,14 +87,39 @@ def cpu_baseline(sample_cols: int):
     t1 = time.perf_counter()
     orc.merkle_commit(evs, [n] * sample_cols)
     t2 = time.perf_counter()
-    return {
-        "value": sample_cols * (1 << n) / (t2 - t0),
-        "unit": "elems/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{sample_cols} of {COLS_PER_GPU} columns x 2^{n}: oracle CFFT evaluate ({t1 - t0:.2f} s) + "
-                  f"Blake2s Merkle commit over them ({t2 - t1:.2f} s), 1 thread; host has {os.cpu_count()} cores",
+    single = {
+        "value": sample_cols * (1 << n) / (t2 - t0), "unit": "elems/s", "cores": 1,
+        "sample": f"{sample_cols} of {COLS_PER_GPU} columns x 2^{n}: CFFT evaluate ({t1 - t0:.2f} s) + Merkle commit over them ({t2 - t1:.2f} s)",
         "cfft_butterflies_per_s": sample_cols * n * (1 << (n - 1)) / (t1 - t0),
+    }
+    cores = os.cpu_count() or 1
+    if threads <= 0:
+        threads = 1
+        while threads * 2 <= min(cores, 32):
+            threads *= 2
+    if threads < 2:
+        return dict(single, kind="port", sample=single["sample"] + f", 1 thread; host has {cores} cores")
+    all_cols = cols + [splitmix_column(100 + c, 1 << n) for c in range(sample_cols, COLS_PER_GPU)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        t3 = time.perf_counter()
+        evs = list(pool.map(lambda c: orc.cfft_evaluate(c, n, half, tw, n - 1), all_cols))
+        t4 = time.perf_counter()
+        rows = (1 << n) // threads
+        lg = n - (threads.bit_length() - 1)
+        sub = list(pool.map(lambda r: orc.merkle_commit([e[r * rows:(r + 1) * rows] for e in evs], [lg] * len(evs))[1], range(threads)))
+        while len(sub) > 1:
+            sub = [hashlib.blake2s(sub[2 * i] + sub[2 * i + 1]).digest() for i in range(len(sub) // 2)]
+        t5 = time.perf_counter()
+    return {
+        "value": COLS_PER_GPU * (1 << n) / (t5 - t3),
+        "unit": "elems/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"the full step ({COLS_PER_GPU} columns x 2^{n}) on {threads} threads of the host's {cores} cores: column-parallel CFFT "
+                  f"({t4 - t3:.2f} s) + row-sharded Merkle commit ({t5 - t4:.2f} s); {threads * (t5 - t3):.0f} core-seconds",
+        "cfft_butterflies_per_s": COLS_PER_GPU * n * (1 << (n - 1)) / (t4 - t3),
+        "root": sub[0].hex()[:16],
+        "single_thread": single,
     }
 
 
