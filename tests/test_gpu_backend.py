@@ -946,3 +946,21 @@ def test_config3_full_size_quotients_and_inverse():
     inv = T.HipBackend().batchInverse(sec)
     prod = T.HipBackend().secureMul(sec, inv).to_numpy()
     assert (prod[0] == 1).all() and not prod[1].any() and not prod[2].any() and not prod[3].any()
+
+
+def test_simd_twiddle_dbls_export():
+    """backend/simd/fft/index.ts:161-203: layer l = doubled x of the first half of coset.repeated_double(l), bit-reversed;
+    the inverse variant holds doubled inverses."""
+    coset = T.Coset.half_odds(6)
+    tree = T.precompute_twiddles(coset)
+    dbls, idbls = T.get_twiddle_dbls(tree), T.get_twiddle_dbls(tree, inverse=True)
+    assert [len(d) for d in dbls] == [32, 16, 8, 4, 2, 1]
+    cur = coset
+    for l, (d, di) in enumerate(zip(dbls, idbls)):
+        half = cur.size() // 2
+        xs = [cur.at(i).x for i in range(half)]
+        lg = half.bit_length() - 1
+        want = [(xs[T.bit_reverse_index(i, lg)].value * 2) & 0xFFFFFFFF for i in range(half)]
+        assert list(map(int, d)) == want
+        assert list(map(int, di)) == [(xs[T.bit_reverse_index(i, lg)].inverse().value * 2) & 0xFFFFFFFF for i in range(half)]
+        cur = cur.double()

@@ -187,6 +187,31 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
     }
 }
 
+// (1b) bottom layer of exactly 4 columns — every FRI layer (the 4 coordinate columns of a QM31 column): a 16-byte
+//      message, one final block whose words 4..15 are zero.
+__global__ void __launch_bounds__(256) k_merkle_leaf4(const u32 *__restrict__ c0, const u32 *__restrict__ c1, const u32 *__restrict__ c2,
+                                                     const u32 *__restrict__ c3, uint4 *__restrict__ out, size_t n_nodes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 rows = (u32)((n_nodes + stride - 1) / stride);
+    const size_t last_node = n_nodes - 1;
+    size_t nc = min(node0, last_node);
+    u32 a = c0[nc], b = c1[nc], c = c2[nc], d = c3[nc];
+    for (u32 j = 0; j < rows; j++) {
+        const size_t node = node0 + (size_t)j * stride;
+        const size_t nn = min(node + stride, last_node);
+        const u32 na = c0[nn], nb = c1[nn], ncc = c2[nn], nd = c3[nn];      // next node's words in flight during the compression
+        u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+        const u32 m[16] = {a, b, c, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        b2s_compress(h, m, 16u, true);
+        if (node < n_nodes) {
+            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
+            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        a = na; b = nb; c = ncc; d = nd;
+    }
+}
+
 // (2) inner layer without columns: node = Blake2s(left || right), one 64-byte block.
 __global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ prev, uint4 *__restrict__ out, size_t n_nodes) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -416,6 +441,11 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
             case 3: hipLaunchKernelGGL(k_merkle_leaf_static<3>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
             default: hipLaunchKernelGGL(k_merkle_leaf_static<4>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
         }
+        TSTWO_LAUNCH_CHECK();
+        return TSTWO_OK;
+    }
+    if (!prev && n_cols == 4 && !getenv("TSTWO_MERKLE_GENERIC")) {
+        hipLaunchKernelGGL(k_merkle_leaf4, dim3(blocks), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)out, n_nodes);
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
     }

@@ -27,6 +27,23 @@ class TwiddleTree:
         return self.rootCoset.log_size
 
 
+def get_twiddle_dbls(tree: TwiddleTree, inverse: bool = False) -> list:
+    """The SimdBackend's twiddle format (backend/simd/fft/index.ts:161-203, Rust get_twiddle_dbls / get_itwiddle_dbls):
+    per layer l, the doubled x-coordinates (as u32, not reduced) of the first half of coset.repeated_double(l) in
+    bit-reversed order — i.e. level l of the tree times two.  SimdBackend is a CPU backend, so these are host arrays
+    (one download of the tree); lets a SimdBackend reuse a tree generated on the GPU."""
+    buf = (tree.itwiddles if inverse else tree.twiddles).to_numpy()
+    out, off = [], 0
+    for l in range(tree.rootCoset.log_size):
+        n = 1 << (tree.rootCoset.log_size - 1 - l)
+        out.append((buf[off:off + n].astype(np.uint64) * 2 & 0xFFFFFFFF).astype(np.uint32))
+        off += n
+    return out
+
+
+getTwiddleDbls = get_twiddle_dbls
+
+
 def precompute_twiddles(coset: Coset) -> TwiddleTree:
     """precomputeTwiddles (backend/cpu/circle.ts:210-239), generated on the device."""
     n = coset.size()
