@@ -533,3 +533,39 @@ def test_cfft_rejects_sizes_above_28():
     d = dev(rand_column(1, 16))
     with pytest.raises(L.TstwoError, match="log_size > 28 is not supported"):
         L.call("tstwo_cfft_evaluate", ptrs([d]), 1, 29, 1, vp(d), 28)
+
+
+def test_null_pointers_are_errors_not_faults():
+    """Every entry point that takes device pointers answers a null with TSTWO_ERR_BAD_ARG before any kernel is launched."""
+    d = dev(rand_column(1, 64))
+    four = L.p4([d.ptr] * 4)
+    bad4 = L.p4([d.ptr, d.ptr, 0, d.ptr])
+    a = L.u32x([1, 0, 0, 0])
+    null_err = pytest.raises(L.TstwoError, match="null")
+    with null_err:
+        L.call("tstwo_cfft_evaluate", L.ptr_array([d.ptr, 0]), 2, 5, 1 << 25, vp(d), 4)
+    with null_err:
+        L.call("tstwo_cfft_interpolate_to", L.ptr_array([0]), L.ptr_array([d.ptr]), 1, 5, 1 << 25, vp(d), 4)
+    with null_err:
+        L.call("tstwo_bit_reverse", L.ptr_array([0]), 1, 64)
+    with null_err:
+        L.call("tstwo_m31_batch_inverse", vp(None), vp(d), 64)
+    with null_err:
+        L.call("tstwo_qm31_mul", four, bad4, four, 64)
+    with null_err:
+        L.call("tstwo_secure_accumulate", bad4, four, 64)
+    with null_err:
+        L.call("tstwo_fri_fold_line", bad4, 6, vp(d), 6, a, four)
+    with null_err:
+        L.call("tstwo_fri_fold_line", four, 6, vp(None), 6, a, four)
+    with null_err:
+        L.call("tstwo_fri_fold_circle_into_line", four, 32, bad4, 6, vp(d), 6, a)
+    with null_err:
+        L.call("tstwo_merkle_commit", L.ptr_array([d.ptr, 0]), L.u32x([6, 6]), 2, vp(d), None)
+    with null_err:
+        L.call("tstwo_merkle_commit", L.ptr_array([d.ptr]), L.u32x([6]), 1, vp(None), None)
+    with null_err:
+        L.call("tstwo_eval_at_point", vp(None), 6, a, a, (C.c_uint32 * 4)())
+    with null_err:
+        L.call("tstwo_poly_extend", vp(d), 6, vp(None), 8)
+    L.sync()

@@ -21,6 +21,8 @@
 //
 // Algorithmic bytes: 8 per element per transform (column read once + written once); real HBM/MALL
 // traffic: 8 per element per pass (+ <= 2 for twiddles).  DESIGN.md §CFFT has the roofline numbers.
+#include <unordered_set>
+
 #include "common.h"
 #include "host_field.h"
 #include <stdlib.h>
@@ -359,10 +361,18 @@ u32 pick_cols_per_wg(size_t tiles, size_t cnt) {
     return cpw;
 }
 
+// Tiles above 64 KiB of LDS need a per-kernel opt-in (160 KiB per CU on gfx950); done once per kernel, not per launch.
+int allow_big_lds(const void *kernel) {
+    static std::unordered_set<const void *> done;
+    if (done.insert(kernel).second)
+        TSTWO_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return TSTWO_OK;
+}
+
 template <typename KernelT, typename... Args>
 int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t tiles, u32 *const *cols, size_t n_cols, Args... args) {
     Context &c = ctx();
-    TSTWO_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
     if (getenv("TSTWO_CFFT_TRACE")) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, (const void *)kernel);
@@ -397,7 +407,7 @@ int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, 
     const size_t tiles = (size_t)1 << (n - 14);
     const size_t lds_bytes = ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32);
     auto kernel = fast::k_cfft_a<false, K, EXT>;
-    TSTWO_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
     for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
         size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
         ColPtrs cp, sp;
@@ -461,6 +471,7 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     if (n_cols == 0) return TSTWO_OK;
     if (!cols) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
     Context &c = ctx();
+    TSTWO_REQUIRE_TABLE(cols, n_cols);
     const u32 N = 1u << n;
     const u32 n_inv = host::inv(N % M31_P);
     if (n <= 2) {
@@ -548,6 +559,7 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
     TSTWO_REQUIRE_READY();
     if (n_cols == 0) return TSTWO_OK;
     if (!src || !dst) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
+    TSTWO_REQUIRE_TABLE(src, n_cols); TSTWO_REQUIRE_TABLE(dst, n_cols);
     if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
     const bool tiled = log_size >= kMaxLogTileB && log_size <= 28 && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
                        !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_OOP");
@@ -567,7 +579,7 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
             const size_t tiles = (size_t)1 << (log_size - 13);
             const size_t lds = (((size_t)1 << 13) + ((size_t)1 << 8) + ((size_t)1 << 9)) * sizeof(u32);
             auto kernel = fast::k_cfft_b<true, 13, true>;
-            TSTWO_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
             for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
                 size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
                 ColPtrs cp, sp;
@@ -602,6 +614,7 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
     TSTWO_REQUIRE_READY();
     if (n_cols == 0) return TSTWO_OK;
     if (!polys || !out) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
+    TSTWO_REQUIRE_TABLE(polys, n_cols); TSTWO_REQUIRE_TABLE(out, n_cols);
     if (log_size < log_poly) return set_error(TSTWO_ERR_LOG_SIZE, "log size too small");
     if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
     const u32 ext = log_size - log_poly;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <initializer_list>
 #include <string>
 
 #include "../../include/tstwo_hip.h"
@@ -54,5 +55,20 @@ constexpr int kMaxHashCols = 256;        // Merkle: columns absorbed per launch 
 struct HashColPtrs { const u32 *p[kMaxHashCols]; };
 struct Soa4 { u32 *p[4]; };
 struct CSoa4 { const u32 *p[4]; };
+
+// Argument hygiene of the C ABI: a null device pointer must come back as an error, never reach a kernel (a GPU page fault
+// can take the whole node down).
+inline bool has_null(std::initializer_list<const void *> l) {
+    for (const void *p : l) if (!p) return true;
+    return false;
+}
+template <typename T>
+inline bool table_has_null(T *const *t, size_t n) {
+    if (!t) return n > 0;
+    for (size_t i = 0; i < n; i++) if (!t[i]) return true;
+    return false;
+}
+#define TSTWO_REQUIRE_PTRS(...) do { if (::tstwo::has_null({__VA_ARGS__})) return set_error(TSTWO_ERR_BAD_ARG, "null device pointer"); } while (0)
+#define TSTWO_REQUIRE_TABLE(t, n) do { if (::tstwo::table_has_null((t), (n))) return set_error(TSTWO_ERR_BAD_ARG, "null device pointer in table"); } while (0)
 
 }  // namespace tstwo

@@ -281,6 +281,7 @@ int tstwo_m31_neg(const u32 *a, u32 *out, size_t n) { return launch_binop<OP_NEG
 int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_PTRS(in, out);
     // elements per lane: enough lanes to fill the chip first, then amortise the 37-multiplication Fermat chain
     if (n >= ((size_t)1 << 24)) {
         constexpr int K = 16;
@@ -297,6 +298,7 @@ int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
 int tstwo_cm31_batch_inverse(const u32 *const in[2], u32 *const out[2], size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_TABLE(in, 2); TSTWO_REQUIRE_TABLE(out, 2);
     constexpr int K = 8;
     size_t T = (n + K - 1) / K;
     CSoa2 i2 = {{in[0], in[1]}};
@@ -308,6 +310,7 @@ int tstwo_cm31_batch_inverse(const u32 *const in[2], u32 *const out[2], size_t n
 int tstwo_qm31_batch_inverse(const u32 *const in[4], u32 *const out[4], size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4);
     constexpr int K = 8;
     size_t T = (n + K - 1) / K;
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
@@ -320,6 +323,7 @@ int tstwo_qm31_batch_inverse(const u32 *const in[4], u32 *const out[4], size_t n
 int tstwo_qm31_mul(const u32 *const a[4], const u32 *const b[4], u32 *const out[4], size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_TABLE(a, 4); TSTWO_REQUIRE_TABLE(b, 4); TSTWO_REQUIRE_TABLE(out, 4);
     CSoa4 a4 = {{a[0], a[1], a[2], a[3]}}, b4 = {{b[0], b[1], b[2], b[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
     hipLaunchKernelGGL(k_qm31_mul, dim3(capped_blocks(n, 256)), dim3(256), 0, ctx().stream, a4, b4, o4, n);
@@ -330,6 +334,7 @@ int tstwo_qm31_mul(const u32 *const a[4], const u32 *const b[4], u32 *const out[
 int tstwo_secure_accumulate(u32 *const col[4], const u32 *const other[4], size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_TABLE(col, 4); TSTWO_REQUIRE_TABLE(other, 4);
     Soa4 c4 = {{col[0], col[1], col[2], col[3]}};
     CSoa4 o4 = {{other[0], other[1], other[2], other[3]}};
     hipLaunchKernelGGL(k_secure_accumulate, dim3(capped_blocks(n, 256), 4), dim3(256), 0, ctx().stream, c4, o4, n);
@@ -343,6 +348,7 @@ int tstwo_bit_reverse(u32 *const *cols, size_t n_cols, size_t n) {
     u32 log_n = 0;
     while (((size_t)1 << log_n) < n) log_n++;
     if (log_n == 0 || n_cols == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_TABLE(cols, n_cols);
     for (size_t base = 0; base < n_cols; base += kMaxColsPerLaunch) {
         size_t cnt = n_cols - base < (size_t)kMaxColsPerLaunch ? n_cols - base : (size_t)kMaxColsPerLaunch;
         ColPtrs cp;
@@ -373,6 +379,8 @@ int tstwo_twiddles_build(u32 coset_initial, u32 log_size, u32 *tw, u32 *itw) {
 
 int tstwo_poly_extend(const u32 *src, u32 log_src, u32 *dst, u32 log_dst) {
     TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_PTRS(src, dst);
+    if (log_dst > 31) return set_error(TSTWO_ERR_BAD_ARG, "extend: log size out of range");
     if (log_dst < log_src) return set_error(TSTWO_ERR_LOG_SIZE, "log size too small");
     size_t ns = (size_t)1 << log_src, nd = (size_t)1 << log_dst;
     hipLaunchKernelGGL(k_extend, dim3(capped_blocks(nd, 256)), dim3(256), 0, ctx().stream, src, ns, dst, nd);

@@ -164,6 +164,7 @@ extern "C" {
 
 int tstwo_fri_fold_line_tw(const u32 *const in[4], u32 log_n, const u32 *inv_x, const u32 alpha[4], u32 *const out[4]) {
     TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4); TSTWO_REQUIRE_PTRS(inv_x, alpha);
     if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
     if (log_n > 31) return set_error(TSTWO_ERR_BAD_ARG, "fold_line: log size out of range");
     size_t n_out = (size_t)1 << (log_n - 1);
@@ -175,6 +176,7 @@ int tstwo_fri_fold_line_tw(const u32 *const in[4], u32 log_n, const u32 *inv_x, 
 }
 
 int tstwo_fri_fold_line(const u32 *const in[4], u32 log_n, const u32 *itw, u32 tw_log, const u32 alpha[4], u32 *const out[4]) {
+    if (!itw) return set_error(TSTWO_ERR_BAD_ARG, "null device pointer");
     if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
     if (tw_log > 31 || log_n > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     // level of the tree whose coset has log size log_n: 2^(log_n-1) entries starting 2^log_n before the end
@@ -185,6 +187,7 @@ int tstwo_fri_fold_line(const u32 *const in[4], u32 log_n, const u32 *itw, u32 t
 static int fold_circle_common(bool from_tree, u32 *const dst[4], size_t dst_len, const u32 *const src[4], u32 log_n,
                               const u32 *twp, const u32 alpha[4]) {
     TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_TABLE(dst, 4); TSTWO_REQUIRE_TABLE(src, 4); TSTWO_REQUIRE_PTRS(twp, alpha);
     if (log_n == 0 || log_n > 31 || (((size_t)1 << log_n) >> 1) != dst_len)
         return set_error(TSTWO_ERR_LEN_MISMATCH, "fold_circle_into_line: Length mismatch between src and dst after considering fold step.");
     host::Q a = to_hq(alpha);
@@ -207,6 +210,7 @@ int tstwo_fri_fold_circle_into_line_tw(u32 *const dst[4], size_t dst_len, const 
 
 int tstwo_fri_fold_circle_into_line(u32 *const dst[4], size_t dst_len, const u32 *const src[4], u32 log_n,
                                     const u32 *itw, u32 tw_log, const u32 alpha[4]) {
+    if (!itw) return set_error(TSTWO_ERR_BAD_ARG, "null device pointer");
     if (log_n == 0 || log_n > 31 || (((size_t)1 << log_n) >> 1) != dst_len)
         return set_error(TSTWO_ERR_LEN_MISMATCH, "fold_circle_into_line: Length mismatch between src and dst after considering fold step.");
     if (log_n < 3) return set_error(TSTWO_ERR_BAD_ARG, "fold_circle_into_line: log_n < 3 needs explicit twiddles (tstwo_fri_fold_circle_into_line_tw)");
@@ -230,6 +234,7 @@ static int check_shard(const char *fn, u32 log_n, size_t row_offset, size_t n_ro
 int tstwo_fri_fold_line_rows(const u32 *const in[4], u32 log_n, size_t row_offset, size_t n_rows, const u32 *itw, u32 tw_log,
                              const u32 alpha[4], u32 *const out[4]) {
     TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4); TSTWO_REQUIRE_PTRS(itw, alpha);
     if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
     if (tw_log > 31 || log_n > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     int rc = check_shard("fold_line_rows", log_n, row_offset, n_rows);
@@ -245,6 +250,7 @@ int tstwo_fri_fold_line_rows(const u32 *const in[4], u32 log_n, size_t row_offse
 int tstwo_fri_fold_circle_into_line_rows(u32 *const dst[4], const u32 *const src[4], u32 log_n, size_t row_offset, size_t n_rows,
                                          const u32 *itw, u32 tw_log, const u32 alpha[4]) {
     TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_TABLE(dst, 4); TSTWO_REQUIRE_TABLE(src, 4); TSTWO_REQUIRE_PTRS(itw, alpha);
     if (log_n < 3 || log_n > 31) return set_error(TSTWO_ERR_BAD_ARG, "fold_circle_into_line_rows: log_n must be in [3, 31]");
     if (tw_log > 31 || log_n - 1 > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     int rc = check_shard("fold_circle_into_line_rows", log_n, row_offset, n_rows);
@@ -263,6 +269,7 @@ int tstwo_fri_fold_circle_into_line_rows(u32 *const dst[4], const u32 *const src
 int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32 lambda[4]) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return set_error(TSTWO_ERR_BAD_ARG, "decompose: empty evaluation");
+    TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4); TSTWO_REQUIRE_PTRS(lambda);
     Context &c = ctx();
     int rc = ensure_scratch(64);
     if (rc) return rc;
@@ -295,6 +302,7 @@ int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32
 
 int tstwo_eval_at_point(const u32 *coeffs, u32 log_size, const u32 px[4], const u32 py[4], u32 out[4]) {
     TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_PTRS(coeffs, px, py, out);
     if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: log size out of range");
     Context &c = ctx();
     if (log_size == 0) {   // circle.ts:53-59
@@ -352,6 +360,7 @@ int tstwo_eval_at_point_batch(const u32 *const *coeffs, size_t n_cols, u32 log_s
     TSTWO_REQUIRE_READY();
     if (n_cols == 0) return TSTWO_OK;
     if (!coeffs || !out) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: null argument");
+    TSTWO_REQUIRE_TABLE(coeffs, n_cols); TSTWO_REQUIRE_PTRS(px, py);
     if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: log size out of range");
     if (log_size == 0 || n_cols == 1) {
         for (size_t i = 0; i < n_cols; i++) {

@@ -561,6 +561,7 @@ int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *
         (n_query_sets && (!query_logs || !queries || !n_queries)))
         return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: null argument");
     if (max_log > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");
+    TSTWO_REQUIRE_TABLE(cols, n_cols);
     for (size_t i = 0; i < n_cols; i++)
         if (col_log_sizes[i] > max_log) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: column larger than the tree");
     std::vector<const void *> h_src, q_src, w_src;
@@ -622,12 +623,15 @@ int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *
 int tstwo_merkle_commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size_t n_cols, uint8_t *out) {
     TSTWO_REQUIRE_READY();
     if (n_cols && !cols) return set_error(TSTWO_ERR_BAD_ARG, "merkle: null column table");
+    TSTWO_REQUIRE_TABLE(cols, n_cols);
     return commit_layer(log_size, prev, cols, n_cols, out);
 }
 
 int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_cols, uint8_t *layers, uint8_t root[32]) {
     TSTWO_REQUIRE_READY();
     if (!layers) return set_error(TSTWO_ERR_BAD_ARG, "merkle: null layers buffer");
+    if (n_cols && !log_sizes) return set_error(TSTWO_ERR_BAD_ARG, "merkle: null log size table");
+    TSTWO_REQUIRE_TABLE(cols, n_cols);
     u32 max_log = 0;
     for (size_t i = 0; i < n_cols; i++) {
         if (log_sizes[i] > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");

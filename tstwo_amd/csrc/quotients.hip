@@ -146,6 +146,8 @@ int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const 
                                const u32 *prx, const u32 *pry, const u32 *pix, const u32 *piy, u32 *const out[4]) {
     TSTWO_REQUIRE_READY();
     if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "quotients: log size out of range");
+    TSTWO_REQUIRE_TABLE(cols, n_cols); TSTWO_REQUIRE_TABLE(out, 4);
+    if (n_batches) TSTWO_REQUIRE_PTRS(batch_off, col_idx, abc, batch_coeff, prx, pry, pix, piy);
     Context &c = ctx();
     const size_t n_entries = n_batches ? batch_off[n_batches] : 0;
     for (size_t j = 0; j < n_entries; j++)
