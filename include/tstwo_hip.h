@@ -137,6 +137,18 @@ int tstwo_fri_fold_line(const uint32_t *const in[4], uint32_t log_n, const uint3
  * dst_len != 2^(log_n-1) -> TSTWO_ERR_LEN_MISMATCH. */
 int tstwo_fri_fold_circle_into_line(uint32_t *const dst[4], size_t dst_len, const uint32_t *const src[4],
                                     uint32_t log_n, const uint32_t *itw, uint32_t tw_log, const uint32_t alpha[4]);
+/* Variants for a commit loop that never leaves the device: alpha_dev points to 4 words (16-byte aligned) in device memory,
+ * written earlier on the stream by tstwo_channel_mix_root_draw_felt.  Same results as the by-value calls. */
+int tstwo_fri_fold_line_dev(const uint32_t *const in[4], uint32_t log_n, const uint32_t *itw, uint32_t tw_log,
+                            const uint32_t *alpha_dev, uint32_t *const out[4]);
+int tstwo_fri_fold_circle_into_line_dev(uint32_t *const dst[4], size_t dst_len, const uint32_t *const src[4],
+                                        uint32_t log_n, const uint32_t *itw, uint32_t tw_log, const uint32_t *alpha_dev);
+/* Blake2sChannel on the device (channel/blake2.ts:25-224; Rust draw semantics).  chan = 10 words of device memory:
+ * digest[8], n_challenges, n_sent (upload the host channel's state, download it back when done).
+ * root != NULL: mix_root (vcs/blake2_merkle.ts:28-31) of the 32 bytes at `root` (device memory, e.g. byte 0 of a
+ * tstwo_merkle_commit layers buffer).  felt != NULL: draw_felt into the 4 words at `felt` (device memory).
+ * Asynchronous: later calls on the stream see the results; nothing reaches the host. */
+int tstwo_channel_mix_root_draw_felt(uint32_t *chan, const uint8_t *root, uint32_t *felt);
 /* Row shards of a FRI layer for multi-GPU provers (SURVEY.md 8e "contiguous row sharding"; output i of fri.ts:120-192
  * depends on inputs 2i, 2i+1 only).  `in`/`src` hold input rows [2*row_offset, 2*(row_offset+n_rows)) and `out`/`dst`
  * output rows [row_offset, row_offset+n_rows) of a layer of 2^log_n input rows.  row_offset and n_rows are multiples

@@ -247,8 +247,17 @@ def test_blake2s_channel_mirror():
     a = c.draw_felt()
     assert c.n_sent == 1 and all(0 <= v < P for v in a.tup())
     c2 = T.Blake2sChannel(); c2.mix_u64(4)
-    assert c2.draw_felt() == a and c2.draw_felt() == c.draw_felt()      # second felt comes from the same 8-word draw
-    assert c.n_sent == 1
+    assert c2.draw_felt() == a
+    b = c.draw_felt()                                                   # Rust semantics: a fresh 8-word draw per felt
+    assert c.n_sent == 2 and b != a and c2.draw_felt() == b
+    ct = T.Blake2sChannel(ts_compat=True); ct.mix_u64(4)
+    assert ct.draw_felt() == a                                          # TS port: second felt = the 4 words left in the queue ...
+    ct.mix_root(bytes(32))
+    stale = ct.draw_felt()
+    assert ct.n_sent == 0                                               # ... even across a mix (no new draw happened)
+    c3 = T.Blake2sChannel(); c3.mix_u64(4)
+    f9 = c3.draw_felts(9)
+    assert c3.n_sent == 5 and f9[0] == a and f9[1] == stale             # draw_felts: consecutive words of the same draws
     d0 = c.digest()
     c.mix_root(bytes(range(32)))
     import hashlib

@@ -964,3 +964,50 @@ def test_simd_twiddle_dbls_export():
         assert list(map(int, d)) == want
         assert list(map(int, di)) == [(xs[T.bit_reverse_index(i, lg)].inverse().value * 2) & 0xFFFFFFFF for i in range(half)]
         cur = cur.double()
+
+
+# ---------------------------------------------------------------- device-resident Blake2sChannel
+def test_device_channel_matches_host_channel():
+    """tstwo_channel_mix_root_draw_felt == Blake2sChannel.mix_root + draw_felt (hashlib), including the counters."""
+    host = T.Blake2sChannel()
+    host.mix_u64(12345)
+    ref = host.clone()
+    dch = T.DeviceChannel(host)
+    roots = [bytes((7 * i + k) & 0xFF for k in range(32)) for i in range(5)]
+    felts = L.DeviceBuffer(16 * 8)
+    want = []
+    for i, r in enumerate(roots):
+        rb = L.DeviceBuffer(32)
+        rb.upload(np.frombuffer(r, dtype=np.uint8))
+        dch.mix_root_draw_felt(rb.ptr, felts.ptr + 16 * i)
+        ref.mix_root(r)
+        want.append(ref.draw_felt().tup())
+    dch.mix_root_draw_felt(None, felts.ptr + 16 * 5)            # draw only
+    want.append(ref.draw_felt().tup())
+    got = felts.download(count=24).reshape(6, 4)
+    assert [tuple(int(x) for x in row) for row in got] == want
+    dch.sync_to_host()
+    assert (host.digest(), host.n_challenges, host.n_sent) == (ref.digest(), ref.n_challenges, ref.n_sent)
+    with pytest.raises(ValueError, match="Rust draw semantics"):
+        T.DeviceChannel(T.Blake2sChannel(ts_compat=True))
+
+
+@pytest.mark.parametrize("logs", [[10], [11, 9, 7]])
+def test_fri_commit_device_transcript_equals_host_transcript(logs):
+    """FriProver.commit with the device channel (no read-back per layer) and with the host channel produce the same roots,
+    the same last layer and leave the channel in the same state; decommit + verify work on the device-committed prover."""
+    cfg = T.FriConfig(2, 2, 6)
+    cols, tw = [], None
+    for i, lg in enumerate(logs):
+        c, t = _secure_low_degree_eval(lg - 2, 2, 23000 + 10 * i)
+        cols.append(c)
+        tw = tw or t
+    ch_d, ch_h = T.Blake2sChannel(), T.Blake2sChannel()
+    pd = T.FriProver.commit(ch_d, cfg, cols, tw, device_channel=True)
+    ph = T.FriProver.commit(ch_h, cfg, cols, tw, device_channel=False)
+    assert pd.first_layer.merkle_tree.root() == ph.first_layer.merkle_tree.root()
+    assert [l.merkle_tree.root() for l in pd.inner_layers] == [l.merkle_tree.root() for l in ph.inner_layers]
+    assert [c.tup() for c in pd.last_layer_poly.coeffs] == [c.tup() for c in ph.last_layer_poly.coeffs]
+    assert (ch_d.digest(), ch_d.n_challenges, ch_d.n_sent) == (ch_h.digest(), ch_h.n_challenges, ch_h.n_sent)
+    proof, positions = pd.decommit(ch_d)
+    _fri_verify(cfg, proof, [lg - 2 for lg in logs], _query_evals(cols, positions), positions)

@@ -49,6 +49,9 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_fri_fold_line_tw: { args: [P, u32, u64, P, P], returns: i32 },
   tstwo_fri_fold_circle_into_line: { args: [P, u64, P, u32, u64, u32, P], returns: i32 },
   tstwo_fri_fold_circle_into_line_tw: { args: [P, u64, P, u32, u64, P], returns: i32 },
+  tstwo_fri_fold_line_dev: { args: [P, u32, u64, u32, u64, P], returns: i32 },
+  tstwo_fri_fold_circle_into_line_dev: { args: [P, u64, P, u32, u64, u32, u64], returns: i32 },
+  tstwo_channel_mix_root_draw_felt: { args: [u64, u64, u64], returns: i32 },
   tstwo_fri_fold_line_rows: { args: [P, u32, u64, u64, u64, u32, P, P], returns: i32 },
   tstwo_fri_fold_circle_into_line_rows: { args: [P, P, u32, u64, u64, u64, u32, P], returns: i32 },
   tstwo_fri_decompose: { args: [P, u64, P, P], returns: i32 },

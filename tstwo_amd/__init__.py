@@ -6,7 +6,7 @@ the HIP library is missing or no GPU is present, and never touches oracle/.
 """
 from . import _lib  # noqa: F401
 from .backend import HipBackend, HipColumn, SecureColumnByCoords, shard_columns  # noqa: F401
-from .channel import Blake2sChannel, HipGrindOps, grind  # noqa: F401
+from .channel import Blake2sChannel, DeviceChannel, HipGrindOps, grind  # noqa: F401
 from .circle import (CanonicCoset, CircleDomain, CirclePoint, CirclePointIndex, Coset, LineDomain,  # noqa: F401
                      M31_CIRCLE_GEN, SECURE_FIELD_CIRCLE_GEN, bit_reverse_index)
 from .fields import CM31, M31, P, QM31  # noqa: F401

@@ -69,6 +69,9 @@ _SIGS = {
     "tstwo_fri_fold_circle_into_line": [P4, C.c_size_t, P4, C.c_uint32, vp, C.c_uint32, u32p],
     "tstwo_fri_fold_line_tw": [P4, C.c_uint32, vp, u32p, P4],
     "tstwo_fri_fold_circle_into_line_tw": [P4, C.c_size_t, P4, C.c_uint32, vp, u32p],
+    "tstwo_fri_fold_line_dev": [P4, C.c_uint32, vp, C.c_uint32, vp, P4],
+    "tstwo_fri_fold_circle_into_line_dev": [P4, C.c_size_t, P4, C.c_uint32, vp, C.c_uint32, vp],
+    "tstwo_channel_mix_root_draw_felt": [vp, vp, vp],
     "tstwo_fri_fold_line_rows": [P4, C.c_uint32, C.c_size_t, C.c_size_t, vp, C.c_uint32, u32p, P4],
     "tstwo_fri_fold_circle_into_line_rows": [P4, P4, C.c_uint32, C.c_size_t, C.c_size_t, vp, C.c_uint32, u32p],
     "tstwo_fri_decompose": [P4, C.c_size_t, P4, u32p],

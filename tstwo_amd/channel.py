@@ -13,13 +13,18 @@ SECURE_EXTENSION_DEGREE = 4
 
 
 class Blake2sChannel:
-    def __init__(self):
+    """ts_compat: the TS port keeps the 4 unused base felts of a draw_felt() in a queue that survives later mix_*() calls
+    (blake2.ts:177-184), so every second challenge does not depend on what was mixed since — Rust draws 8 fresh base felts
+    per draw_felt and drops 4.  Default = Rust (sound Fiat-Shamir); ts_compat=True reproduces the TS queue."""
+
+    def __init__(self, ts_compat: bool = False):
         self._digest = bytes(32)              # Blake2sHash default: all zeros (blake2.ts:42-49)
         self.n_challenges = 0
         self.n_sent = 0
+        self.ts_compat = ts_compat
         self._base_queue = []
 
-    create = classmethod(lambda cls: cls())
+    create = classmethod(lambda cls, ts_compat=False: cls(ts_compat))
 
     def digest(self) -> bytes:
         return self._digest
@@ -30,7 +35,7 @@ class Blake2sChannel:
         self.n_sent = 0
 
     def clone(self) -> "Blake2sChannel":
-        c = Blake2sChannel()
+        c = Blake2sChannel(self.ts_compat)
         c._digest, c.n_challenges, c.n_sent, c._base_queue = self._digest, self.n_challenges, self.n_sent, list(self._base_queue)
         return c
 
@@ -75,15 +80,54 @@ class Blake2sChannel:
             if all(x < 2 * P for x in u32s):
                 return [M31.reduce(x) for x in u32s]
 
-    def draw_felt(self) -> QM31:                   # blake2.ts:177-184
+    def draw_felt(self) -> QM31:                   # Rust Blake2sChannel::draw_felt; TS variant blake2.ts:177-184
+        if not self.ts_compat:
+            return QM31.from_u32_unchecked(*[m.value for m in self._draw_base_felts()[:SECURE_EXTENSION_DEGREE]])
         while len(self._base_queue) < SECURE_EXTENSION_DEGREE:
             self._base_queue += self._draw_base_felts()
         a = self._base_queue[:4]
         del self._base_queue[:4]
         return QM31.from_u32_unchecked(*[m.value for m in a])
 
-    def draw_felts(self, n: int):
-        return [self.draw_felt() for _ in range(n)]
+    def draw_felts(self, n: int):                  # blake2.ts:186-208 (= Rust): a queue local to the call, leftovers dropped
+        out, queue = [], []
+        for _ in range(n):
+            while len(queue) < SECURE_EXTENSION_DEGREE:
+                queue += self._draw_base_felts()
+            out.append(QM31.from_u32_unchecked(*[m.value for m in queue[:4]]))
+            del queue[:4]
+        return out
+
+
+class DeviceChannel:
+    """The channel's state (digest, n_challenges, n_sent) mirrored in 40 bytes of device memory, so that a launch sequence
+    (FRI commit: tree -> mix_root -> draw_felt -> fold -> tree ...) never waits for the host.  Rust draw semantics only."""
+
+    def __init__(self, host: Blake2sChannel):
+        import numpy as np
+
+        from . import _lib as L
+        if host.ts_compat:
+            raise ValueError("the device channel implements the Rust draw semantics only")
+        self.host = host
+        self.buf = L.DeviceBuffer(64)
+        st = np.zeros(16, dtype=np.uint32)
+        st[:8] = np.frombuffer(host.digest(), dtype="<u4")
+        st[8], st[9] = host.n_challenges, host.n_sent
+        self.buf.upload(st)
+
+    def mix_root_draw_felt(self, root_ptr: int | None, felt_ptr: int | None) -> None:
+        """mix_root of the 32 bytes at device address root_ptr, then draw_felt into the 4 words at felt_ptr (either may be None)."""
+        import ctypes as C
+
+        from . import _lib as L
+        L.call("tstwo_channel_mix_root_draw_felt", C.c_void_p(self.buf.ptr), C.c_void_p(root_ptr or 0), C.c_void_p(felt_ptr or 0))
+
+    def sync_to_host(self) -> Blake2sChannel:
+        st = self.buf.download(count=10)
+        self.host._digest = st[:8].astype("<u4").tobytes()
+        self.host.n_challenges, self.host.n_sent = int(st[8]), int(st[9])
+        return self.host
 
 
 class HipGrindOps:

@@ -27,7 +27,9 @@ __device__ __forceinline__ qm31 load_pair_fold(const CSoa4 &in, size_t i, u32 t,
 }
 
 // fri.ts:120-152.  inv_x[i] = domain.at(bitrev(2i)).x^-1.
-__global__ void __launch_bounds__(256) k_fold_line(CSoa4 in, Soa4 out, size_t n_out, const u32 *__restrict__ inv_x, qm31 alpha) {
+__global__ void __launch_bounds__(256) k_fold_line(CSoa4 in, Soa4 out, size_t n_out, const u32 *__restrict__ inv_x, qm31 alpha,
+                                                  const qm31 *__restrict__ alpha_dev) {
+    if (alpha_dev) alpha = *alpha_dev;          // alpha drawn by the device channel (uniform load)
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
         qm31 f0;
@@ -41,7 +43,8 @@ __global__ void __launch_bounds__(256) k_fold_line(CSoa4 in, Soa4 out, size_t n_
 // layer-1 slice of the inverse tree: +-seg1[(i>>1)^1], negative iff (i ^ (i>>1)) & 1.
 template <bool FROM_TREE>
 __global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t n_out, const u32 *__restrict__ twp,
-                                                    qm31 alpha, qm31 alpha_sq) {
+                                                    qm31 alpha, qm31 alpha_sq, const qm31 *__restrict__ alpha_dev) {
+    if (alpha_dev) { alpha = *alpha_dev; alpha_sq = qm31_mul(alpha, alpha); }
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
         u32 t;
@@ -170,7 +173,7 @@ int tstwo_fri_fold_line_tw(const u32 *const in[4], u32 log_n, const u32 *inv_x, 
     size_t n_out = (size_t)1 << (log_n - 1);
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
-    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, to_q(alpha));
+    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, to_q(alpha), (const qm31 *)nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -196,9 +199,9 @@ static int fold_circle_common(bool from_tree, u32 *const dst[4], size_t dst_len,
     CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
     unsigned blocks = capped_blocks(dst_len, 256);
     if (from_tree)
-        hipLaunchKernelGGL(k_fold_circle<true>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2));
+        hipLaunchKernelGGL(k_fold_circle<true>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2), (const qm31 *)nullptr);
     else
-        hipLaunchKernelGGL(k_fold_circle<false>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2));
+        hipLaunchKernelGGL(k_fold_circle<false>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2), (const qm31 *)nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -217,6 +220,42 @@ int tstwo_fri_fold_circle_into_line(u32 *const dst[4], size_t dst_len, const u32
     if (tw_log > 31 || log_n - 1 > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (log_n - 1));   // layer-1 slice, 2^(log_n-2) entries
     return fold_circle_common(true, dst, dst_len, src, log_n, seg1, alpha);
+}
+
+// ---- alpha in device memory (written by tstwo_channel_mix_root_draw_felt on the same stream): the FRI commit loop then
+// needs no host round trip between a layer's Merkle tree and the next fold.
+int tstwo_fri_fold_line_dev(const u32 *const in[4], u32 log_n, const u32 *itw, u32 tw_log, const u32 *alpha_dev, u32 *const out[4]) {
+    TSTWO_REQUIRE_READY();
+    if (log_n == 0) return set_error(TSTWO_ERR_TOO_SMALL, "fold_line: Evaluation too small, must have at least 2 elements.");
+    if (tw_log > 31 || log_n > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4); TSTWO_REQUIRE_PTRS(itw, alpha_dev);
+    if (((uintptr_t)alpha_dev) & 15) return set_error(TSTWO_ERR_BAD_ARG, "fold: alpha must be 16-byte aligned");
+    const size_t n_out = (size_t)1 << (log_n - 1);
+    const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << log_n);
+    CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, seg, qm31{0, 0, 0, 0},
+                       (const qm31 *)alpha_dev);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_fri_fold_circle_into_line_dev(u32 *const dst[4], size_t dst_len, const u32 *const src[4], u32 log_n, const u32 *itw, u32 tw_log,
+                                        const u32 *alpha_dev) {
+    TSTWO_REQUIRE_READY();
+    if (log_n == 0 || log_n > 31 || (((size_t)1 << log_n) >> 1) != dst_len)
+        return set_error(TSTWO_ERR_LEN_MISMATCH, "fold_circle_into_line: Length mismatch between src and dst after considering fold step.");
+    if (log_n < 3) return set_error(TSTWO_ERR_BAD_ARG, "fold_circle_into_line: log_n < 3 needs explicit twiddles (tstwo_fri_fold_circle_into_line_tw)");
+    if (tw_log > 31 || log_n - 1 > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    TSTWO_REQUIRE_TABLE(dst, 4); TSTWO_REQUIRE_TABLE(src, 4); TSTWO_REQUIRE_PTRS(itw, alpha_dev);
+    if (((uintptr_t)alpha_dev) & 15) return set_error(TSTWO_ERR_BAD_ARG, "fold: alpha must be 16-byte aligned");
+    const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (log_n - 1));
+    Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
+    CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
+    hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(dst_len, 256)), dim3(256), 0, ctx().stream, d4, s4, dst_len, seg1,
+                       qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha_dev);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
 }
 
 // ---- row shards (contiguous row sharding of FRI layers, no exchange): the pointers address this
@@ -242,7 +281,7 @@ int tstwo_fri_fold_line_rows(const u32 *const in[4], u32 log_n, size_t row_offse
     const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << log_n) + row_offset;
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
-    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, i4, o4, n_rows, seg, to_q(alpha));
+    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, i4, o4, n_rows, seg, to_q(alpha), (const qm31 *)nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -261,7 +300,7 @@ int tstwo_fri_fold_circle_into_line_rows(u32 *const dst[4], const u32 *const src
     host::Q a2 = host::qmul(a, a);
     Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
     CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
-    hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, d4, s4, n_rows, seg1, to_q(a), to_q(a2));
+    hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, d4, s4, n_rows, seg1, to_q(a), to_q(a2), (const qm31 *)nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }

@@ -393,6 +393,68 @@ int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
     return TSTWO_OK;
 }
 
+// ---- Blake2sChannel on the device (channel/blake2.ts:25-224, Rust semantics).  State = 10 words: digest[8], n_challenges,
+// n_sent.  One quad of lanes runs the (latency-bound) compressions; used by the FRI commit loop so that a layer's root
+// never has to travel to the host before the next fold can be launched.
+__device__ __forceinline__ void chan_hash64(const u32 (&m)[16], u32 j, u32 (&digest)[8]) {
+    u32 lo, hi;
+    b2s_quad_block64(m, j, lo, hi);
+    // every lane of the quad needs the whole digest: word k lives in lane k & 3 (lo for k < 4, hi for k >= 4)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        digest[k] = (u32)__builtin_amdgcn_readlane((int)lo, k);
+        digest[4 + k] = (u32)__builtin_amdgcn_readlane((int)hi, k);
+    }
+}
+// mix_root (vcs/blake2_merkle.ts:28-31): digest <- H(digest || root), n_challenges += 1, n_sent <- 0; then (optionally)
+// draw_felt (blake2.ts:158-184): H(digest || LE32(n_sent) || 0^28) until all 8 words < 2P; felt = first 4 words reduced.
+__global__ void __launch_bounds__(64) k_channel_mix_draw(u32 *__restrict__ chan, const u32 *__restrict__ root, u32 *__restrict__ felt,
+                                                        u32 do_mix, u32 do_draw) {
+    const u32 j = threadIdx.x & 3;
+    u32 d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = chan[k];
+    u32 n_chal = chan[8], n_sent = chan[9];
+    if (do_mix) {
+        u32 m[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { m[k] = d[k]; m[8 + k] = root[k]; }
+        chan_hash64(m, j, d);
+        n_chal += 1;
+        n_sent = 0;
+    }
+    if (do_draw) {
+        u32 w[8];
+        bool ok = false;
+        // retry probability per round ~ 2^-28; the loop is bounded so that the kernel always terminates (64 rejections in a
+        // row have probability 2^-1792)
+        for (int tries = 0; tries < 64 && !ok; tries++) {
+            u32 m[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { m[k] = d[k]; m[8 + k] = 0; }
+            m[8] = n_sent;
+            n_sent += 1;
+            chan_hash64(m, j, w);
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; k++) ok = ok && (w[k] < 2u * M31_P);
+        }
+        if (threadIdx.x < 4) {
+            u32 v = w[0];
+            v = threadIdx.x == 1 ? w[1] : v;
+            v = threadIdx.x == 2 ? w[2] : v;
+            v = threadIdx.x == 3 ? w[3] : v;
+            felt[threadIdx.x] = v >= M31_P ? v - M31_P : v;       // M31.reduce of a value < 2P
+        }
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) chan[k] = d[k];
+        chan[8] = n_chal;
+        chan[9] = n_sent;
+    }
+}
+
 struct GatherItem { const u32 *src; unsigned long long idx; };
 __global__ void __launch_bounds__(256) k_gather_words(const GatherItem *__restrict__ items, u32 words, size_t total, u32 *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -617,6 +679,18 @@ int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *
     if (rc) return rc;
     for (size_t i = 0; i < q_src.size(); i++) queried_values[i] = vals[i];
     for (size_t i = 0; i < w_src.size(); i++) column_witness[i] = vals[q_src.size() + i];
+    return TSTWO_OK;
+}
+
+// Device-resident Blake2sChannel (state: 10 words = digest[8], n_challenges, n_sent).  root: 32 bytes in device memory
+// (e.g. offset 0 of a tstwo_merkle_commit layers buffer) or NULL to skip the mix; felt: 4 words in device memory or NULL
+// to skip the draw.  Nothing is synchronised: the next kernel on the stream can consume `felt`.
+int tstwo_channel_mix_root_draw_felt(u32 *chan, const uint8_t *root, u32 *felt) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_PTRS(chan);
+    if ((((uintptr_t)root) & 3) || (((uintptr_t)felt) & 3)) return set_error(TSTWO_ERR_BAD_ARG, "channel: unaligned pointer");
+    hipLaunchKernelGGL(k_channel_mix_draw, dim3(1), dim3(64), 0, ctx().stream, chan, (const u32 *)root, felt, root ? 1u : 0u, felt ? 1u : 0u);
+    TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
 

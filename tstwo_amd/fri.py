@@ -55,6 +55,33 @@ class HipFriOps:
                                               for i in range(dst.len())])
             L.call("tstwo_fri_fold_circle_into_line_tw", dst.values.ptrs(), dst.len(), src.values.ptrs(), n, _vp(inv.ptr), a)
 
+    # ---- alpha in device memory (drawn by the device channel): same folds, no host round trip
+    @staticmethod
+    def can_fold_on_device(domain, twiddles: TwiddleTree | None) -> bool:
+        if twiddles is None:
+            return False
+        if isinstance(domain, CircleDomain):
+            return domain.log_size() >= 3 and domain.halfCoset.is_doubling_of(twiddles.rootCoset)
+        return domain.logSize() >= 1 and domain.coset().is_doubling_of(twiddles.rootCoset)
+
+    @staticmethod
+    def fold_line_dev(eval_: LineEvaluation, alpha_ptr: int, twiddles: TwiddleTree) -> LineEvaluation:
+        n = eval_.len()
+        if n < 2:
+            raise ValueError("fold_line: Evaluation too small, must have at least 2 elements.")
+        domain = eval_.domain()
+        out = SecureColumnByCoords.uninitialized(n // 2)
+        L.call("tstwo_fri_fold_line_dev", eval_.values.ptrs(), domain.logSize(), _vp(twiddles.itwiddles.ptr), twiddles.log_size,
+               C.c_void_p(alpha_ptr), out.ptrs())
+        return LineEvaluation(domain.double(), out)
+
+    @staticmethod
+    def fold_circle_into_line_dev(dst: LineEvaluation, src: SecureEvaluation, alpha_ptr: int, twiddles: TwiddleTree) -> None:
+        if (src.domain.size() >> CIRCLE_TO_LINE_FOLD_STEP) != dst.len():
+            raise ValueError("fold_circle_into_line: Length mismatch between src and dst after considering fold step.")
+        L.call("tstwo_fri_fold_circle_into_line_dev", dst.values.ptrs(), dst.len(), src.values.ptrs(), src.domain.log_size(),
+               _vp(twiddles.itwiddles.ptr), twiddles.log_size, C.c_void_p(alpha_ptr))
+
     @staticmethod
     def decompose(eval_: SecureEvaluation):
         n = eval_.len()

@@ -8,7 +8,9 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+from . import _lib as L
 from .backend import SecureColumnByCoords
+from .channel import DeviceChannel
 from .circle import Coset, LineDomain, bit_reverse_index
 from .queries import Queries, get_query_positions_by_log_size
 from .fields import M31, P, QM31
@@ -208,7 +210,7 @@ class FriProver:
         self.config, self.first_layer, self.inner_layers, self.last_layer_poly = config, first_layer, inner_layers, last_layer_coeffs
 
     @staticmethod
-    def commit(channel, config: FriConfig, columns, twiddles: TwiddleTree) -> "FriProver":
+    def commit(channel, config: FriConfig, columns, twiddles: TwiddleTree, device_channel: bool = True) -> "FriProver":
         """columns: SecureEvaluation list, canonic domains, strictly decreasing sizes (fri.ts:644-674)."""
         if not columns:
             raise ValueError("no columns")
@@ -217,32 +219,55 @@ class FriProver:
         for a, b in zip(columns, columns[1:]):
             if a.domain.size() <= b.domain.size():
                 raise ValueError("column sizes not decreasing")
-        # first layer: one tree over every column's coordinate columns (Rust FriFirstLayerProver::new), root -> channel
-        coord_cols = [cc for c in columns for cc in c.values.columns]
-        first_tree = MerkleProver.commit(coord_cols)
-        channel.mix_root(first_tree.root())
-        first_layer = FriFirstLayerProver(columns, first_tree)
-
+        # Device transcript: when every fold can take its twiddles from the tree and the channel has Rust semantics, the whole
+        # commit loop is one launch sequence — roots are mixed and alphas drawn by the device channel, nothing is read back
+        # until the last layer.  Otherwise: the host channel, one 32-byte read-back per layer.
         folded = lambda v: v.domain.size() >> CIRCLE_TO_LINE_FOLD_STEP
         first_log = (folded(columns[0])).bit_length() - 1
+        on_device = (device_channel and not getattr(channel, "ts_compat", False) and hasattr(channel, "_digest")
+                     and all(HipFriOps.can_fold_on_device(c.domain, twiddles) for c in columns)
+                     and HipFriOps.can_fold_on_device(LineDomain(Coset.half_odds(first_log)), twiddles))
+        dch = DeviceChannel(channel) if on_device else None
+        alphas = L.DeviceBuffer(16 * (first_log + 2)) if on_device else None
+        n_alpha = [0]
+
+        def mix_and_draw(tree):
+            """mix_root(tree.root()) then draw_felt(); returns alpha as a QM31 (host path) or a device address (device path)."""
+            if on_device:
+                ptr = alphas.ptr + 16 * n_alpha[0]
+                n_alpha[0] += 1
+                dch.mix_root_draw_felt(tree.root_ptr(), ptr)
+                return ptr
+            channel.mix_root(tree.root())
+            return channel.draw_felt()
+
+        fold_line_ = HipFriOps.fold_line_dev if on_device else HipFriOps.fold_line
+        fold_circle_ = HipFriOps.fold_circle_into_line_dev if on_device else HipFriOps.fold_circle_into_line
+
+        # first layer: one tree over every column's coordinate columns (Rust FriFirstLayerProver::new), root -> channel
+        coord_cols = [cc for c in columns for cc in c.values.columns]
+        first_tree = MerkleProver.commit(coord_cols, sync_root=not on_device)
+        alpha = mix_and_draw(first_tree)
+        first_layer = FriFirstLayerProver(columns, first_tree)
+
         layer_eval = LineEvaluation.new_zero(LineDomain(Coset.half_odds(first_log)))
         it = iter(columns)
-        alpha = channel.draw_felt()
-        HipFriOps.fold_circle_into_line(layer_eval, next(it), alpha, twiddles)
+        fold_circle_(layer_eval, next(it), alpha, twiddles)
         nxt = next(it, None)
         inner = []
         while layer_eval.len() > config.last_layer_domain_size():
-            tree = MerkleProver.commit(layer_eval.values.columns)           # FriInnerLayerProver::new
-            channel.mix_root(tree.root())
-            alpha = channel.draw_felt()
+            tree = MerkleProver.commit(layer_eval.values.columns, sync_root=not on_device)      # FriInnerLayerProver::new
+            alpha = mix_and_draw(tree)
             layer = FriInnerLayerProver(layer_eval, tree)
-            layer_eval = HipFriOps.fold_line(layer_eval, alpha, twiddles)
+            layer_eval = fold_line_(layer_eval, alpha, twiddles)
             if nxt is not None and folded(nxt) == layer_eval.len():
-                HipFriOps.fold_circle_into_line(layer_eval, nxt, alpha, twiddles)
+                fold_circle_(layer_eval, nxt, alpha, twiddles)
                 nxt = next(it, None)
             inner.append(layer)
         if nxt is not None:
             raise ValueError("not all columns were consumed")                # Rust: assert!(columns.is_empty())
+        if on_device:
+            dch.sync_to_host()                                               # the host channel continues from the device state
         # last layer (fri.ts:718-754)
         if layer_eval.len() != config.last_layer_domain_size():
             raise ValueError("last layer domain size mismatch")

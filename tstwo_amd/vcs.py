@@ -55,8 +55,9 @@ class MerkleProver:
         self.layers, self._buf, self._root = layers, buf, root
 
     @staticmethod
-    def commit(columns, ops=None) -> "MerkleProver":
-        """columns: HipColumn list of power-of-two lengths (mixed sizes allowed; order kept within a size)."""
+    def commit(columns, ops=None, sync_root: bool = True) -> "MerkleProver":
+        """columns: HipColumn list of power-of-two lengths (mixed sizes allowed; order kept within a size).
+        sync_root=False: nothing is read back (root() fetches the 32 bytes on first use) — for callers that keep going on the device."""
         log_sizes = []
         for c in columns:
             n = c.len()
@@ -65,13 +66,19 @@ class MerkleProver:
             log_sizes.append(n.bit_length() - 1)
         max_log = max(log_sizes) if columns else 0
         buf = L.DeviceBuffer(32 * ((2 << max_log) - 1))
-        root = (C.c_uint8 * 32)()
+        root = (C.c_uint8 * 32)() if sync_root else None
         L.call("tstwo_merkle_commit", L.ptr_array([c.ptr for c in columns]), L.u32x(log_sizes), len(columns), _vp(buf.ptr), root)
         layers = [DeviceHashLayer(buf, 1 << k, 32 * ((1 << k) - 1)) for k in range(max_log + 1)]
-        return MerkleProver(layers, buf, bytes(root))
+        return MerkleProver(layers, buf, bytes(root) if sync_root else None)
 
     def root(self) -> bytes:
+        if self._root is None:                      # committed asynchronously (sync_root=False): fetch the 32 bytes now
+            self._root = self._buf.download(np.uint8, 32).tobytes()
         return self._root
+
+    def root_ptr(self) -> int:
+        """Device address of the root (byte 0 of the layers buffer) for consumers that stay on the device."""
+        return self._buf.ptr
 
     def decommit(self, queriesPerLogSize: dict, columns) -> tuple:
         """MerkleProver.decommit (vcs/prover.ts:32-109): returns (queried_values, MerkleDecommitment).
