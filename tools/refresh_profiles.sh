@@ -20,11 +20,14 @@ rocprofv3 --kernel-trace --output-format csv -d $O/stats_configs -o configs -- p
 echo "stats configs done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/pmc_target.py > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/pmc_target.py > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES --output-format csv -d $O/pmc_sq1 -o s1 -- python3 $R/tools/pmc_target.py > $O/pmc_sq1.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq2 -o s2 -- python3 $R/tools/pmc_target.py > $O/pmc_sq2.log 2>&1
 echo "pmc done"
 cd $R
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/cfft_pmc.json
+python3 tools/sq_summary.py $O/pmc_sq1 $O/pmc_sq2 > $O/sq_counters.json
 python3 tools/prof_summary.py $O/stats > $O/bench_kernel_summary.txt
 python3 tools/prof_summary.py $O/stats_configs > $O/configs_kernel_summary.txt
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
-rm -rf $O/stats $O/stats_configs $O/pmc_fetch $O/pmc_write      # raw traces are large; summaries are what is kept
+rm -rf $O/stats $O/stats_configs $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces are large; summaries are what is kept
 ls -la $O
