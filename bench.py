@@ -306,7 +306,7 @@ def main():
                                   "frac": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK}},
             "device": L.device_name(),
         }
-        if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE:
+        if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_cols)
         else:
             out["cpu_baseline"] = None
