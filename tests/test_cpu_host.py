@@ -343,3 +343,29 @@ def test_line_poly_host():
     assert p.eval_at_point(x).tup() == want.tup()
     with pytest.raises(ValueError, match="coeffs length must be power of two"):
         T.LinePoly(co[:3])
+
+
+def test_blake2s_channel_rust_digest_kats():
+    """test/channel/channel_exact_rust_tests.test.ts:84-120 — digests copied from the Rust tests (test_mix_u64, test_mix_u32s)."""
+    c = T.Blake2sChannel()
+    c.mix_u64(0x1111222233334444)
+    c2 = T.Blake2sChannel()
+    c2.mix_u32s([0x33334444, 0x11112222])
+    assert c.digest() == c2.digest() == bytes([
+        0xbc, 0x9e, 0x3f, 0xc1, 0xd2, 0x4e, 0x88, 0x97, 0x95, 0x6d, 0x33, 0x59, 0x32, 0x73, 0x97, 0x24, 0x9d, 0x6b, 0xca, 0xcd, 0x22,
+        0x4d, 0x92, 0x74, 0x4, 0xe7, 0xba, 0x4a, 0x77, 0xdc, 0x6e, 0xce])
+    c3 = T.Blake2sChannel()
+    c3.mix_u32s([1, 2, 3, 4, 5, 6, 7, 8, 9])
+    assert c3.digest() == bytes([
+        0x70, 0x91, 0x76, 0x83, 0x57, 0xbb, 0x1b, 0xb3, 0x34, 0x6f, 0xda, 0xb6, 0xb3, 0x57, 0xd7, 0xfa, 0x46, 0xb8, 0xfb, 0xe3, 0x2c,
+        0x2e, 0x43, 0x24, 0xa0, 0xff, 0xc2, 0x94, 0xcb, 0xf9, 0xa1, 0xc7])
+    # channel_time (Rust test_channel_time): draw_random_bytes -> n_sent 1; draw_felts(9) -> 5 more draws
+    c4 = T.Blake2sChannel()
+    c4.draw_random_bytes()
+    assert (c4.n_challenges, c4.n_sent) == (0, 1)
+    c4.draw_felts(9)
+    assert (c4.n_challenges, c4.n_sent) == (0, 6)
+    with pytest.raises(TypeError):
+        c4.mix_u32s([-1])
+    with pytest.raises(TypeError):
+        c4.mix_u64(-1)
