@@ -369,3 +369,10 @@ def test_blake2s_channel_rust_digest_kats():
         c4.mix_u32s([-1])
     with pytest.raises(TypeError):
         c4.mix_u64(-1)
+
+
+def test_get_query_positions_by_log_size_kat():
+    """test/fri/get_query_positions_by_log_size.test.ts:5-12."""
+    q = T.Queries.from_positions([1, 3, 5, 7], 3)
+    res = T.get_query_positions_by_log_size(q, {3, 2})
+    assert res[3] == [1, 3, 5, 7] and res[2] == [0, 1, 2, 3]
