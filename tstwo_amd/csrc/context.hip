@@ -49,10 +49,37 @@ int ensure_scratch(size_t bytes) {
     c.scratch_bytes = want;
     return TSTWO_OK;
 }
+int small_d2h(void *host_dst, const void *dev_src, size_t bytes) {
+    Context &c = g_ctx;
+    if (bytes == 0) return TSTWO_OK;
+    if (!c.pinned || bytes > kPinnedBytes) {
+        TSTWO_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        return TSTWO_OK;
+    }
+    TSTWO_HIP(hipMemcpyAsync(c.pinned, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    memcpy(host_dst, c.pinned, bytes);
+    return TSTWO_OK;
+}
+int small_h2d(void *dev_dst, const void *host_src, size_t bytes) {
+    Context &c = g_ctx;
+    if (bytes == 0) return TSTWO_OK;
+    if (!c.pinned || bytes > kPinnedBytes) {
+        TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.stream));
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        return TSTWO_OK;
+    }
+    // the staging buffer is reused by the next call, so the copy must have left it before we return
+    memcpy(c.pinned, host_src, bytes);
+    TSTWO_HIP(hipMemcpyAsync(dev_dst, c.pinned, bytes, hipMemcpyHostToDevice, c.stream));
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    return TSTWO_OK;
+}
 int read_and_clear_flag(u32 *value) {
     Context &c = g_ctx;
-    TSTWO_HIP(hipMemcpyAsync(value, c.flag, sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    int rc = small_d2h(value, c.flag, sizeof(u32));
+    if (rc) return rc;
     if (*value) TSTWO_HIP(hipMemsetAsync(c.flag, 0, sizeof(u32), c.stream));
     return TSTWO_OK;
 }
@@ -134,6 +161,7 @@ int tstwo_init(int device) {
     TSTWO_HIP(hipMemcpy(c.gen_pow2, tab, sizeof(tab), hipMemcpyHostToDevice));
     TSTWO_HIP(hipMalloc((void **)&c.flag, 64));
     TSTWO_HIP(hipMemset(c.flag, 0, 64));
+    if (hipHostMalloc(&c.pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; (void)hipGetLastError(); }
     c.ready = true;
     return TSTWO_OK;
 }
@@ -147,6 +175,7 @@ int tstwo_shutdown(void) {
     g_pool.live.clear();
     if (c.gen_pow2) (void)hipFree(c.gen_pow2);
     if (c.flag) (void)hipFree(c.flag);
+    if (c.pinned) (void)hipHostFree(c.pinned);
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = Context();
@@ -235,6 +264,7 @@ int tstwo_free(void *dev) {
 int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes) {
     TSTWO_REQUIRE_READY();
     if (bytes == 0) return TSTWO_OK;
+    if (bytes <= kPinnedBytes) return small_h2d(dev_dst, host_src, bytes);
     TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
     return TSTWO_OK;
@@ -242,6 +272,7 @@ int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes) {
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes) {
     TSTWO_REQUIRE_READY();
     if (bytes == 0) return TSTWO_OK;
+    if (bytes <= kPinnedBytes) return small_d2h(host_dst, dev_src, bytes);
     TSTWO_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
     return TSTWO_OK;

@@ -322,8 +322,7 @@ int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32
     hipLaunchKernelGGL(k_half_sums, dim3(blocks, 4, 2), dim3(256), 0, c.stream, i4, n, sums);
     TSTWO_LAUNCH_CHECK();
     unsigned long long h[8];
-    TSTWO_HIP(hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    { int rc2 = small_d2h(h, sums, sizeof(h)); if (rc2) return rc2; }
     // lambda = (a_sum - b_sum) / n  (n == 1: first half empty -> lambda = -f[0])
     u32 n_inv = host::inv((u32)(n % host::P));
     qm31 lam;
@@ -346,8 +345,7 @@ int tstwo_eval_at_point(const u32 *coeffs, u32 log_size, const u32 px[4], const 
     Context &c = ctx();
     if (log_size == 0) {   // circle.ts:53-59
         u32 v;
-        TSTWO_HIP(hipMemcpyAsync(&v, coeffs, 4, hipMemcpyDeviceToHost, c.stream));
-        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        { int rc2 = small_d2h(&v, coeffs, 4); if (rc2) return rc2; }
         out[0] = v; out[1] = out[2] = out[3] = 0;
         return TSTWO_OK;
     }
@@ -386,8 +384,7 @@ int tstwo_eval_at_point(const u32 *coeffs, u32 log_size, const u32 px[4], const 
     }
     TSTWO_LAUNCH_CHECK();
     qm31 r;
-    TSTWO_HIP(hipMemcpyAsync(&r, src, sizeof(r), hipMemcpyDeviceToHost, c.stream));
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    { int rc2 = small_d2h(&r, src, sizeof(r)); if (rc2) return rc2; }
     out[0] = r.a; out[1] = r.b; out[2] = r.c; out[3] = r.d;
     return TSTWO_OK;
 }

@@ -577,12 +577,11 @@ int tstwo_grind_blake2s(const uint8_t digest[32], u32 pow_bits, uint64_t start_n
         if (base - start_nonce >= (1ull << 22)) batch = 1ull << 26;
         if (none - base < batch) batch = none - base;
         if (batch == 0) return set_error(TSTWO_ERR_BAD_ARG, "grind: nonce space exhausted");
-        TSTWO_HIP(hipMemcpyAsync(best, &none, sizeof(none), hipMemcpyHostToDevice, c.stream));
+        TSTWO_HIP(hipMemsetAsync(best, 0xFF, sizeof(none), c.stream));      // none = all ones
         hipLaunchKernelGGL(k_grind, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, c.stream, d, pow_bits, base, batch, best);
         TSTWO_LAUNCH_CHECK();
         unsigned long long found = none;
-        TSTWO_HIP(hipMemcpyAsync(&found, best, sizeof(found), hipMemcpyDeviceToHost, c.stream));
-        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        { int rc2 = small_d2h(&found, best, sizeof(found)); if (rc2) return rc2; }
         if (found != none) { *nonce_out = found; return TSTWO_OK; }
         base += batch;
     }
@@ -599,16 +598,13 @@ int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, u32 words, 
     if (rc) return rc;
     GatherItem *h = new GatherItem[n_items];
     for (size_t i = 0; i < n_items; i++) { h[i].src = (const u32 *)srcs[i]; h[i].idx = idx[i]; }
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
-    hipError_t e = hipMemcpy(c.scratch, h, n_items * sizeof(GatherItem), hipMemcpyHostToDevice);
+    rc = small_h2d(c.scratch, h, n_items * sizeof(GatherItem));     // stream-ordered behind whatever still reads the scratch
     delete[] h;
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(gather items)");
+    if (rc) return rc;
     u32 *d_out = (u32 *)((unsigned char *)c.scratch + items_bytes);
     hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(total, 256)), dim3(256), 0, c.stream, (const GatherItem *)c.scratch, words, total, d_out);
     TSTWO_LAUNCH_CHECK();
-    TSTWO_HIP(hipMemcpyAsync(host_out, d_out, total * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
-    return TSTWO_OK;
+    return small_d2h(host_out, d_out, total * sizeof(u32));
 }
 
 // MerkleProver.decommit (vcs/prover.ts:32-109) against device-resident layers and columns: the walk over the layers
@@ -745,8 +741,8 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
     delete[] lc;
     if (rc) return rc;
     if (root) {
-        TSTWO_HIP(hipMemcpyAsync(root, layers, 32, hipMemcpyDeviceToHost, ctx().stream));
-        TSTWO_HIP(hipStreamSynchronize(ctx().stream));
+        int rc2 = small_d2h(root, layers, 32);
+        if (rc2) return rc2;
     }
     return TSTWO_OK;
 }

@@ -184,8 +184,8 @@ int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const 
     }
     int rc = ensure_scratch(blob.size());
     if (rc) return rc;
-    TSTWO_HIP(hipStreamSynchronize(c.stream));   // nothing in flight may still read the scratch blob
-    TSTWO_HIP(hipMemcpy(c.scratch, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    rc = small_h2d(c.scratch, blob.data(), blob.size());   // stream-ordered: nothing in flight still reads the scratch when it lands
+    if (rc) return rc;
     const u32 *const *d_cols = (const u32 *const *)c.scratch;
     const BatchConst *d_b = (const BatchConst *)((unsigned char *)c.scratch + ptr_bytes);
     const Entry *d_e = (const Entry *)((unsigned char *)c.scratch + ptr_bytes + bc_bytes);
