@@ -2,6 +2,7 @@
 packages/core/test/backend/backend.test.ts, test/backend/cpu/circle.test.ts, test/poly/circleEvaluation.test.ts,
 test/fri.test.ts, test/backend/cpu/fri.test.ts, test/vcs/prover.test.ts, test/backend/cpu/quotients.test.ts."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1011,3 +1012,65 @@ def test_fri_commit_device_transcript_equals_host_transcript(logs):
     assert (ch_d.digest(), ch_d.n_challenges, ch_d.n_sent) == (ch_h.digest(), ch_h.n_challenges, ch_h.n_sent)
     proof, positions = pd.decommit(ch_d)
     _fri_verify(cfg, proof, [lg - 2 for lg in logs], _query_evals(cols, positions), positions)
+
+
+_SHARDED_FRI_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["TSTWO_ROOT"])
+import numpy as np
+import torch.distributed as dist
+import tstwo_amd as T
+from tstwo_amd.fri_sharded import fri_commit_row_sharded
+from tstwo_amd.distributed import shard_rows
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+T._lib.init(0)                                   # both ranks share the one GPU of the test box
+LOGD, BLOW = 9, 2
+n = LOGD + BLOW
+domain = T.CanonicCoset(n).circleDomain()
+tw = T.precompute_twiddles(domain.halfCoset)
+polys = [T.HipCirclePoly(np.random.default_rng(31000 + k).integers(0, T.P, size=1 << LOGD, dtype=np.uint32)) for k in range(4)]
+evs = T.evaluate_polynomials(polys, domain, tw)
+full = [e.values.to_numpy() for e in evs]
+s, c = shard_rows(1 << n, world, rank)
+shard = T.SecureColumnByCoords.from_numpy([f[s:s + c] for f in full])
+cfg = T.FriConfig(0, BLOW, 5)          # last layer of 4 rows: the tail of the commit must switch to replicated
+ch = T.Blake2sChannel()
+layers, last = fri_commit_row_sharded(ch, cfg, shard, n, rank, world, tw)
+# single-GPU reference on the whole column
+ch1 = T.Blake2sChannel()
+col = T.SecureEvaluation(domain, T.SecureColumnByCoords.from_numpy(full))
+p1 = T.FriProver.commit(ch1, cfg, [col], tw)
+want_roots = [p1.first_layer.merkle_tree.root()] + [l.merkle_tree.root() for l in p1.inner_layers]
+assert [l.root for l in layers] == want_roots, (rank, len(layers), len(want_roots))
+assert [x.tup() for x in last.coeffs] == [x.tup() for x in p1.last_layer_poly.coeffs]
+assert ch.digest() == ch1.digest()
+assert (world < 4 or any(l.replicated for l in layers)) and not layers[0].replicated and len(layers[0].subtree_roots) == world
+# this rank's rows of every sharded layer equal the corresponding rows of the single-GPU layer
+for l, ref in zip(layers[1:], p1.inner_layers):
+    if not l.replicated:
+        rs, rc = shard_rows(1 << l.log_size, world, rank)
+        for a, b in zip(l.shard.to_numpy(), ref.evaluation.values.to_numpy()):
+            assert (a == b[rs:rs + rc]).all()
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_fri_commit_row_sharded_matches_single_gpu(tmp_path, world):
+    """SURVEY 8(e) / north_star: FRI layers row-sharded across ranks (here `world` processes sharing the box's one GPU, gloo
+    for the root all-gather) give the single-GPU transcript: same roots, same last layer, same channel state."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker_fri.py"
+    script.write_text(_SHARDED_FRI_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSTWO_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29540 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert f"rank {r} ok" in o

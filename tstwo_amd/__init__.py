@@ -15,6 +15,7 @@ from .fri_prover import (FriConfig, FriLayerProof, FriProof, FriProver, LinePoly
 from .fri_verifier import (CirclePolyDegreeBound, FriVerificationError, FriVerifier, LinePolyDegreeBound,  # noqa: F401
                            SparseEvaluation, accumulate_line, compute_decommitment_positions_and_rebuild_evals)
 from .queries import Queries, get_query_positions_by_log_size  # noqa: F401
+from .fri_sharded import ShardedFriLayer, fri_commit_row_sharded  # noqa: F401
 from .fri import HipFriOps, decompose, fold_circle_into_line, fold_line  # noqa: F401
 from .pcs import (CommitmentSchemeProof, CommitmentSchemeProver, CommitmentTreeProver, PcsConfig, PointSample,  # noqa: F401
                   TreeBuilder, column_sample_batches, compute_fri_quotients)
