@@ -376,3 +376,24 @@ def test_get_query_positions_by_log_size_kat():
     q = T.Queries.from_positions([1, 3, 5, 7], 3)
     res = T.get_query_positions_by_log_size(q, {3, 2})
     assert res[3] == [1, 3, 5, 7] and res[2] == [0, 1, 2, 3]
+
+
+def test_decommit_requests_planner_against_oracle_tree():
+    """vcs.decommit_requests (the pure index walk of vcs/prover.ts:32-109, used by the row-sharded decommit): served from
+    an oracle-built tree it yields a decommitment the verifier accepts; a wrong witness is rejected."""
+    from tstwo_amd.vcs import decommit_requests
+    rng = np.random.default_rng(5)
+    logs = [5, 5, 3, 5, 3]
+    cols = [rng.integers(0, P, size=1 << lg, dtype=np.uint32) for lg in logs]
+    layers, root = orc.merkle_commit(cols, logs)
+    queries = {5: [0, 7, 8, 30], 3: [2, 5]}
+    hreq, qreq, wreq = decommit_requests(5, logs, queries)
+    hashes = [bytes(layers[lg][node]) for lg, node in hreq]
+    queried = [T.M31(int(cols[c][node])) for c, node in qreq]
+    colwit = [T.M31(int(cols[c][node])) for c, node in wreq]
+    dec = T.MerkleDecommitment(hashes, colwit)
+    T.MerkleVerifier(T.Blake2sMerkleHasher, root, logs).verify(queries, queried, dec)
+    assert len(queried) == 4 * 3 + 2 * 2
+    bad = T.MerkleDecommitment([hashes[0][::-1]] + hashes[1:], colwit)
+    with pytest.raises(ValueError, match="Root mismatch"):
+        T.MerkleVerifier(T.Blake2sMerkleHasher, root, logs).verify(queries, queried, bad)

@@ -1052,6 +1052,14 @@ for l, ref in zip(layers[1:], p1.inner_layers):
         rs, rc = shard_rows(1 << l.log_size, world, rank)
         for a, b in zip(l.shard.to_numpy(), ref.evaluation.values.to_numpy()):
             assert (a == b[rs:rs + rc]).all()
+# decommitment of the row-sharded first-layer tree == the single-GPU decommitment
+from tstwo_amd.distributed import decommit_rows_sharded
+queries = {n: sorted(set(int(q) for q in np.random.default_rng(7).integers(0, 1 << n, size=9)))}
+qv, dec = decommit_rows_sharded(layers[0].subtree, layers[0].subtree_roots, shard.columns, [n] * 4, queries, rank, world)
+qv1, dec1 = p1.first_layer.merkle_tree.decommit(queries, col.values.columns)
+assert [v.value for v in qv] == [v.value for v in qv1]
+assert dec.hashWitness == dec1.hashWitness and [v.value for v in dec.columnWitness] == [v.value for v in dec1.columnWitness]
+T.MerkleVerifier(T.Blake2sMerkleHasher, layers[0].root, [n] * 4).verify(queries, qv, dec)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

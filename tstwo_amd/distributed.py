@@ -92,3 +92,58 @@ def fold_circle_into_line_rows(dst_shard, src_shard, log_n: int, rank: int, worl
         raise ValueError("fold_circle_into_line: Length mismatch between src and dst after considering fold step.")
     L.call("tstwo_fri_fold_circle_into_line_rows", dst_shard.ptrs(), src_shard.ptrs(), log_n, start, count,
            _vp(twiddles.itwiddles.ptr), twiddles.log_size, L.u32x(as_q4(alpha)))
+
+
+def decommit_rows_sharded(subtree, subtree_roots, shard_columns_, full_col_log_sizes, queriesPerLogSize: dict, rank: int, world: int,
+                          group=None):
+    """MerkleProver.decommit for a ROW-SHARDED tree (commit_rows_sharded): every rank plans the same global walk
+    (vcs.decommit_requests), serves the requests that fall into its subtree / its rows with two device gathers, and the
+    answers are exchanged with one all-gather of a few hundred bytes.  Levels above the subtree roots are recomputed from
+    the gathered roots.  Returns (queried_values, MerkleDecommitment) identical to the single-GPU decommit."""
+    import hashlib
+
+    import torch.distributed as dist
+
+    from .fields import M31
+    from .vcs import MerkleDecommitment, _gather, decommit_requests
+    log_w = world.bit_length() - 1
+    max_log = max(full_col_log_sizes) if full_col_log_sizes else 0
+    hash_req, queried_req, witness_req = decommit_requests(max_log, list(full_col_log_sizes), queriesPerLogSize)
+    # top of the tree (levels 0..log_w) from the subtree roots, known to every rank
+    top = {log_w: list(subtree_roots)}
+    for lv in range(log_w - 1, -1, -1):
+        top[lv] = [hashlib.blake2s(top[lv + 1][2 * i] + top[lv + 1][2 * i + 1]).digest() for i in range(1 << lv)]
+    mine_h, mine_v = {}, {}
+    dev_h, dev_v = [], []
+    for j, (lg, node) in enumerate(hash_req):
+        if lg <= log_w:
+            continue                                           # served from `top` by everybody
+        local_log = lg - log_w
+        if node >> local_log == rank:
+            dev_h.append((j, subtree.layers[local_log].ptr, node & ((1 << local_log) - 1)))
+    vals_req = [("q", j, c, node) for j, (c, node) in enumerate(queried_req)] + [("w", j, c, node) for j, (c, node) in enumerate(witness_req)]
+    for kind, j, c, node in vals_req:
+        local_log = full_col_log_sizes[c] - log_w
+        if local_log < 0:
+            raise ValueError("row sharding needs every column to have at least `world` rows")
+        if node >> local_log == rank:
+            dev_v.append(((kind, j), shard_columns_[c].ptr, node & ((1 << local_log) - 1)))
+    hw = _gather([(p, i) for _, p, i in dev_h], 8)
+    for k, (j, _, _) in enumerate(dev_h):
+        mine_h[j] = hw[8 * k:8 * k + 8].tobytes()
+    vw = _gather([(p, i) for _, p, i in dev_v], 1)
+    for k, (key, _, _) in enumerate(dev_v):
+        mine_v[key] = int(vw[k])
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine_h, mine_v), group=group)
+    else:
+        gathered = [(mine_h, mine_v)]
+    all_h, all_v = {}, {}
+    for h, v in gathered:
+        all_h.update(h)
+        all_v.update(v)
+    hashes = [top[lg][node] if lg <= log_w else all_h[j] for j, (lg, node) in enumerate(hash_req)]
+    queried = [M31(all_v[("q", j)]) for j in range(len(queried_req))]
+    colwit = [M31(all_v[("w", j)]) for j in range(len(witness_req))]
+    return queried, MerkleDecommitment(hashes, colwit)

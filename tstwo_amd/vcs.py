@@ -151,6 +151,43 @@ class MerkleProver:
         return queried, dec
 
 
+def decommit_requests(max_log: int, col_log_sizes, queriesPerLogSize: dict) -> tuple:
+    """The walk of MerkleProver.decommit (vcs/prover.ts:32-109) as pure index logic: returns
+    (hash_req [(layer_log, node)], queried_req [(column_index, node)], witness_req [(column_index, node)]) in the order the
+    decommitment lists them.  Columns keep the caller's order within a size (stable sort by size, like the reference)."""
+    order = sorted(range(len(col_log_sizes)), key=lambda i: -col_log_sizes[i])
+    col_i = 0
+    hash_req, queried_req, witness_req = [], [], []
+    last_nodes = []
+    for log in range(max_log, -1, -1):
+        layer_cols = []
+        while col_i < len(order) and col_log_sizes[order[col_i]] == log:
+            layer_cols.append(order[col_i])
+            col_i += 1
+        cur_nodes = []
+        parents = _Peekable(last_nodes)
+        direct = _Peekable(queriesPerLogSize.get(log) or [])
+        while True:
+            node = next_decommitment_node(parents, direct)
+            if node is None:
+                break
+            if log < max_log:
+                for k in (2 * node, 2 * node + 1):
+                    if parents.peek() == k:
+                        parents.next()
+                    else:
+                        hash_req.append((log + 1, k))
+            reqs = [(c, node) for c in layer_cols]
+            if direct.peek() == node:
+                direct.next()
+                queried_req += reqs
+            else:
+                witness_req += reqs
+            cur_nodes.append(node)
+        last_nodes = cur_nodes
+    return hash_req, queried_req, witness_req
+
+
 def _gather(reqs, words: int) -> np.ndarray:
     out = np.empty(len(reqs) * words, dtype=np.uint32)
     if reqs:
