@@ -109,46 +109,15 @@ class MerkleProver:
         return [M31(int(v)) for v in queried[:n_q.value]], dec
 
     def _decommit_walk(self, queriesPerLogSize: dict, columns) -> tuple:
-        """The reference's walk (vcs/prover.ts:32-109) on the host mirror + two tstwo_gather_words calls."""
-        sorted_cols = sorted(columns, key=lambda c: -c.len())                 # stable, like the JS sort
-        col_i = 0
-        hash_req, queried_req, witness_req = [], [], []                       # (device ptr, index) requests, in order
-        last_nodes = []
-        n_layers = len(self.layers)
-        for log in range(n_layers - 1, -1, -1):
-            layer_cols = []
-            while col_i < len(sorted_cols) and sorted_cols[col_i].len() == (1 << log):
-                layer_cols.append(sorted_cols[col_i])
-                col_i += 1
-            child = self.layers[log + 1] if log + 1 < n_layers else None
-            cur_nodes = []
-            parents = _Peekable(last_nodes)
-            direct = _Peekable(queriesPerLogSize.get(log) or [])
-            while True:
-                node = next_decommitment_node(parents, direct)
-                if node is None:
-                    break
-                if child is not None:
-                    for k in (2 * node, 2 * node + 1):
-                        if parents.peek() == k:
-                            parents.next()
-                        else:
-                            hash_req.append((child.ptr, k))
-                reqs = [(c.ptr, node) for c in layer_cols]
-                if direct.peek() == node:
-                    direct.next()
-                    queried_req += reqs
-                else:
-                    witness_req += reqs
-                cur_nodes.append(node)
-            last_nodes = cur_nodes
-        hashes = _gather(hash_req, 8)
-        vals = _gather(queried_req + witness_req, 1)
-        nq = len(queried_req)
-        queried = [M31(int(v)) for v in vals[:nq]]
-        dec = MerkleDecommitment([hashes[8 * i:8 * i + 8].tobytes() for i in range(len(hash_req))],
-                                 [M31(int(v)) for v in vals[nq:]])
-        return queried, dec
+        """The reference's walk (vcs/prover.ts:32-109) planned on the host (decommit_requests) + two tstwo_gather_words calls;
+        kept to cross-check the in-library tstwo_merkle_decommit."""
+        cols = list(columns)
+        hreq, qreq, wreq = decommit_requests(len(self.layers) - 1, [c.len().bit_length() - 1 for c in cols], queriesPerLogSize)
+        hashes = _gather([(self.layers[lg].ptr, node) for lg, node in hreq], 8)
+        vals = _gather([(cols[c].ptr, node) for c, node in qreq + wreq], 1)
+        nq = len(qreq)
+        dec = MerkleDecommitment([hashes[8 * i:8 * i + 8].tobytes() for i in range(len(hreq))], [M31(int(v)) for v in vals[nq:]])
+        return [M31(int(v)) for v in vals[:nq]], dec
 
 
 def decommit_requests(max_log: int, col_log_sizes, queriesPerLogSize: dict) -> tuple:
