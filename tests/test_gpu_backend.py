@@ -1082,3 +1082,17 @@ def test_fri_commit_row_sharded_matches_single_gpu(tmp_path, world):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert f"rank {r} ok" in o
+
+
+def test_bit_reverse_back_and_coset_sub_evaluation():
+    """evaluation.ts:122-136 (bitReverse / bitReverseBack are inverse permutations) and :182-196 (CosetSubEvaluation,
+    test/poly/cosetSubEvaluation.test.ts: wrapping strided view)."""
+    n = 6
+    vals = rand_column(33000, 1 << n)
+    ev = T.HipCircleEvaluation(T.CanonicCoset(n).circleDomain(), vals)
+    br = ev.bitReverse()
+    assert (br.values.to_numpy() == vals[[T.bit_reverse_index(i, n) for i in range(1 << n)]]).all()
+    assert (br.bitReverseBack().values.to_numpy() == vals).all() and (ev.deref().to_numpy() == vals).all()
+    sub = ev.coset_sub_evaluation(5, 3)
+    assert sub.at(0).value == vals[5] and sub.get(30).value == vals[(5 + 90) & 63]
+    assert [m.value for m in sub.gather(range(40))] == [int(vals[(5 + 3 * i) & 63]) for i in range(40)]

@@ -21,7 +21,7 @@ from .pcs import (CommitmentSchemeProof, CommitmentSchemeProver, CommitmentTreeP
                   TreeBuilder, column_sample_batches, compute_fri_quotients)
 from .pcs_verifier import (CommitmentSchemeVerifier, VerificationError, accumulate_row_quotients,  # noqa: F401
                            fri_answers)
-from .poly import (HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureCirclePoly, SecureEvaluation, TwiddleTree,
+from .poly import (CosetSubEvaluation, HipCircleEvaluation, HipCirclePoly, LineEvaluation, SecureCirclePoly, SecureEvaluation, TwiddleTree,
                    domain_line_twiddles_from_tree, get_twiddle_dbls,  # noqa: F401
                    evaluate_polynomials, interpolate_columns, precompute_twiddles)
 from .quotients import (ColumnSampleBatch, accumulate, accumulateQuotients, generate_secure_powers,  # noqa: F401

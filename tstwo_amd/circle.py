@@ -207,7 +207,13 @@ class CanonicCoset:
     def circle_domain(self): return CircleDomain(self.half_coset())
     circleDomain = circle_domain
     def index_at(self, i): return self.coset.index_at(i)
+    indexAt = index_at
     def at(self, i): return self.coset.at(i)
+    def initial_index(self): return self.coset.initial_index          # canonic.ts:78-88
+    initialIndex = initial_index
+    def step_size(self): return self.coset.step_size
+    stepSize = step_size
+    def step(self): return self.coset.step()
 
 
 class LineDomain:

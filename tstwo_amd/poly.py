@@ -226,9 +226,44 @@ class HipCircleEvaluation:
     def toCpu(self): return self.values.toCpu()
 
     def bitReverse(self) -> "HipCircleEvaluation":
+        """evaluation.ts:122-128 (NaturalOrder -> BitReversedOrder): a permuted copy."""
         out = self.values.clone()
         HipBackend().bitReverseColumn(out)
         return HipCircleEvaluation(self.domain, out)
+
+    bitReverseBack = bitReverse                     # evaluation.ts:130-136: the same involution
+    bit_reverse, bit_reverse_back = bitReverse, bitReverse
+
+    def deref(self) -> HipColumn:                   # evaluation.ts:174-176
+        return self.values
+
+    def coset_sub_evaluation(self, offset: int, step: int) -> "CosetSubEvaluation":
+        return CosetSubEvaluation(self.values, offset, step)
+
+
+class CosetSubEvaluation:
+    """CosetSubEvaluation (evaluation.ts:182-196): a strided, wrapping view `values[(offset + i*step) & (len-1)]` of a
+    device column.  `at(i)` reads one word; `gather(indices)` fetches many with one device gather."""
+
+    def __init__(self, evaluation: HipColumn, offset: int, step: int):
+        self.evaluation, self.offset, self.step = evaluation, offset, step
+
+    def _idx(self, index: int) -> int:
+        return (self.offset + index * self.step) & (self.evaluation.len() - 1)
+
+    def at(self, index: int) -> M31:
+        return self.evaluation.at(self._idx(index))
+
+    get = at
+
+    def gather(self, indices) -> list:
+        idx = [self._idx(i) for i in indices]
+        if not idx:
+            return []
+        out = np.empty(len(idx), dtype=np.uint32)
+        L.call("tstwo_gather_words", L.ptr_array([self.evaluation.ptr] * len(idx)), (C.c_uint64 * len(idx))(*idx), 1, len(idx),
+               out.ctypes.data_as(L.u32p))
+        return [M31(int(v)) for v in out]
 
 
 class SecureEvaluation:
