@@ -213,7 +213,7 @@ class CanonicCoset:
     initialIndex = initial_index
     def step_size(self): return self.coset.step_size
     stepSize = step_size
-    def step(self): return self.coset.step()
+    def step(self): return self.coset.step
 
 
 class LineDomain:
