@@ -569,3 +569,47 @@ def test_null_pointers_are_errors_not_faults():
     with null_err:
         L.call("tstwo_poly_extend", vp(d), 6, vp(None), 8)
     L.sync()
+
+
+@pytest.mark.parametrize("n,n_cols", [(1, 200), (2, 130), (6, 300), (12, 150), (13, 70), (15, 97)])
+def test_many_columns_one_launch(n, n_cols):
+    """More than 64 columns go through a device-resident pointer table (one launch per pass instead of one per 64 columns):
+    evaluate, interpolate, the out-of-place / extended variants and bit-reverse agree with the oracle column by column."""
+    tw, itw = build_twiddles(n - 1)
+    half = half_odds(n - 1)
+    cols = [rand_column(40000 + 3 * n + c, 1 << n) for c in range(n_cols)]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_cfft_evaluate", ptrs(d), n_cols, n, half, vp(tw), max(n - 1, 0))
+    otw, oitw = orc.precompute_twiddles(half, n - 1)
+    check = sorted(set([0, 1, 63, 64, 65, n_cols - 1]))
+    ev = {c: host(d[c], 1 << n) for c in check}
+    for c in check:
+        assert (ev[c] == orc.cfft_evaluate(cols[c], n, half, otw, max(n - 1, 0))).all(), c
+    # out-of-place interpolate of all columns gives the inputs back; sources untouched
+    out = [L.DeviceBuffer(4 << n) for _ in cols]
+    L.call("tstwo_cfft_interpolate_to", ptrs(d), ptrs(out), n_cols, n, half, vp(itw), max(n - 1, 0))
+    for c in range(n_cols):
+        assert (host(out[c], 1 << n) == cols[c]).all(), c
+    for c in check:
+        assert (host(d[c], 1 << n) == ev[c]).all()
+    # in-place interpolate as well
+    L.call("tstwo_cfft_interpolate", ptrs(d), n_cols, n, half, vp(itw), max(n - 1, 0))
+    for c in check:
+        assert (host(d[c], 1 << n) == cols[c]).all()
+    # bit-reverse of all columns
+    L.call("tstwo_bit_reverse", ptrs(d), n_cols, 1 << n)
+    for c in check:
+        assert (host(d[c], 1 << n) == orc.bit_reverse(cols[c])).all()
+
+
+def test_many_columns_evaluate_extended():
+    n_poly, n, n_cols = 12, 14, 80
+    tw, _ = build_twiddles(n - 1)
+    polys = [rand_column(41000 + c, 1 << n_poly) for c in range(n_cols)]
+    src = [dev(p) for p in polys]
+    out = [L.DeviceBuffer(4 << n) for _ in polys]
+    L.call("tstwo_cfft_evaluate_extended", ptrs(src), n_poly, ptrs(out), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    otw, _ = orc.precompute_twiddles(half_odds(n - 1), n - 1, inverse=False)
+    for c in (0, 63, 64, 79):
+        ext = np.concatenate([polys[c], np.zeros((1 << n) - (1 << n_poly), dtype=np.uint32)])
+        assert (host(out[c], 1 << n) == orc.cfft_evaluate(ext, n, half_odds(n - 1), otw, n - 1)).all()

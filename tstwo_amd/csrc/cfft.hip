@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
     // ---- prefetch the first column's tile (16 bytes per lane per access)
     uint4 pf[kMaxV4];
     {
-        const u32 *__restrict__ data = cols.p[col0];
+        const u32 *__restrict__ data = colp(cols, col0);
 #pragma unroll
         for (int it = 0; it < kMaxV4; it++) {
             const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
         __syncthreads();
         // ---- prefetch the next column while this one is transformed
         if (col + 1 < col1) {
-            const u32 *__restrict__ next = cols.p[col + 1];
+            const u32 *__restrict__ next = colp(cols, col + 1);
 #pragma unroll
             for (int it = 0; it < kMaxV4; it++) {
                 const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
             }
         }
         // ---- LDS -> global (fused 2^-n scaling on interpolate's last pass)
-        u32 *__restrict__ data = cols.p[col];
+        u32 *__restrict__ data = colp(cols, col);
 #pragma unroll
         for (int it = 0; it < kMaxV4; it++) {
             const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
@@ -266,7 +266,7 @@ template <bool INV>
 __global__ void k_cfft_small(ColPtrs cols, u32 n_cols, u32 n, u32 tx, u32 ty, u32 scale) {
     u32 col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n_cols) return;
-    u32 *v = cols.p[col];
+    u32 *v = colp(cols, col);
     if (n == 1) {
         u32 v0 = v[0], v1 = v[1];
         if (!INV) m31_butterfly(v0, v1, ty);
@@ -321,10 +321,11 @@ int launch_pass_t(u32 *const *cols, size_t n_cols, const PassParams &pp0) {
         lds_attr_set = true;
     }
     const size_t tiles = (size_t)1 << (pp.n - pp.logt);
-    for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
-        size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+    {   // every column in one launch (more than 64: pointer table in device memory)
+        const size_t cnt = n_cols;
         ColPtrs cp;
-        for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[b0 + i];
+        int rc_tab = fill_col_table(cp, cols, n_cols, 0);
+        if (rc_tab) return rc_tab;
         // columns per workgroup: amortise the twiddle staging, but keep >= ~6 workgroups per CU in the grid
         u32 cpw = 4;
         while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)c.n_cus * 6) cpw >>= 1;
@@ -379,10 +380,11 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
         fprintf(stderr, "[cfft] kernel %p threads %d lds %zu: getattr=%d maxDynamicSharedSizeBytes=%d sharedSizeBytes=%zu numRegs=%d maxThreadsPerBlock=%d\n",
                 (const void *)kernel, threads, lds_bytes, (int)e, fa.maxDynamicSharedSizeBytes, fa.sharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock);
     }
-    for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
-        size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+    {
+        const size_t cnt = n_cols;
         ColPtrs cp;
-        for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[b0 + i];
+        int rc_tab = fill_col_table(cp, cols, n_cols, 0);
+        if (rc_tab) return rc_tab;
         const u32 cpw = pick_cols_per_wg(tiles, cnt);
         size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
         if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
@@ -408,10 +410,12 @@ int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, 
     const size_t lds_bytes = ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32);
     auto kernel = fast::k_cfft_a<false, K, EXT>;
     { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
-    for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
-        size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+    {
+        const size_t cnt = n_cols;
         ColPtrs cp, sp;
-        for (size_t i = 0; i < cnt; i++) { cp.p[i] = cols[b0 + i]; sp.p[i] = const_cast<u32 *>(src[b0 + i]); }
+        int rc_tab = fill_col_table(cp, cols, n_cols, 0);
+        if (!rc_tab) rc_tab = fill_col_table(sp, src, n_cols, 1);
+        if (rc_tab) return rc_tab;
         const u32 cpw = pick_cols_per_wg(tiles, cnt);
         size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
         if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
@@ -484,11 +488,11 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
             tx = n == 2 ? host::inv(px) : 0;
             scale = n_inv;
         }
-        for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
-            size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+        {
             ColPtrs cp;
-            for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[b0 + i];
-            hipLaunchKernelGGL(k_cfft_small<INV>, dim3(1), dim3(64), 0, c.stream, cp, (u32)cnt, n, tx, ty, scale);
+            int rc_tab = fill_col_table(cp, cols, n_cols, 0);
+            if (rc_tab) return rc_tab;
+            hipLaunchKernelGGL(k_cfft_small<INV>, dim3((unsigned)((n_cols + 63) / 64)), dim3(64), 0, c.stream, cp, (u32)n_cols, n, tx, ty, scale);
         }
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
@@ -580,10 +584,12 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
             const size_t lds = (((size_t)1 << 13) + ((size_t)1 << 8) + ((size_t)1 << 9)) * sizeof(u32);
             auto kernel = fast::k_cfft_b<true, 13, true>;
             { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
-            for (size_t b0 = 0; b0 < n_cols; b0 += kMaxColsPerLaunch) {
-                size_t cnt = n_cols - b0 < (size_t)kMaxColsPerLaunch ? n_cols - b0 : (size_t)kMaxColsPerLaunch;
+            {
+                const size_t cnt = n_cols;
                 ColPtrs cp, sp;
-                for (size_t i = 0; i < cnt; i++) { cp.p[i] = dst[b0 + i]; sp.p[i] = const_cast<u32 *>(src[b0 + i]); }
+                int rc_tab = fill_col_table(cp, dst, n_cols, 0);
+                if (!rc_tab) rc_tab = fill_col_table(sp, src, n_cols, 1);
+                if (rc_tab) return rc_tab;
                 const u32 cpw = pick_cols_per_wg(tiles, cnt);
                 size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
                 if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");

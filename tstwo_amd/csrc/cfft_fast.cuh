@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
     }
 
     auto src_of = [&](u32 col) -> const u32 * {
-        if constexpr (OOP) return src.p[col] + base;
-        else return cols.p[col] + base;
+        if constexpr (OOP) return colp(src, col) + base;
+        else return colp(cols, col) + base;
     };
     uint4 pf[4];
     {
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
             pf[j] = *reinterpret_cast<const uint4 *>(d + (INV ? 16 * t + 4 * j : 4 * t + j * QT));
     }
     for (u32 col = col0; col < col1; col++) {
-        u32 *__restrict__ data = cols.p[col] + base;
+        u32 *__restrict__ data = colp(cols, col) + base;
         const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
         if (!INV) {
             top_layers<false, true>(pf, ta, tb0, tb1);                    // layers LOGT-1, LOGT-2
@@ -307,12 +307,12 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
             }
         };
         auto src_of = [&](u32 col) -> const u32 * {
-            if constexpr (EXT == 0) return cols.p[col] + base;
-            else return src.p[col] + base;       // the first pass has hi == 0: base only carries bits below the replicated ones
+            if constexpr (EXT == 0) return colp(cols, col) + base;
+            else return colp(src, col) + base;       // the first pass has hi == 0: base only carries bits below the replicated ones
         };
         load_tile(src_of(col0));
         for (u32 col = col0; col < col1; col++) {
-            u32 *__restrict__ data = cols.p[col] + base;
+            u32 *__restrict__ data = colp(cols, col) + base;
             const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
             u32 tt = t;
             asm volatile("" : "+v"(tt));     // opaque per iteration: keeps the 16 scatter addresses out of loop-invariant registers
@@ -366,15 +366,15 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
         u32 pfs[16];
         {
             const u32 tt = t;
-            const u32 *__restrict__ d = cols.p[col0] + base;
+            const u32 *__restrict__ d = colp(cols, col0) + base;
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
                 for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = d[goff(e_final(tt, g, m))];
         }
         for (u32 col = col0; col < col1; col++) {
-            u32 *__restrict__ data = cols.p[col] + base;
-            const u32 *__restrict__ next = cols.p[min(col + 1, col1 - 1)] + base;
+            u32 *__restrict__ data = colp(cols, col) + base;
+            const u32 *__restrict__ next = colp(cols, min(col + 1, col1 - 1)) + base;
             u32 tt = t;
             asm volatile("" : "+v"(tt));
 #pragma unroll

@@ -21,6 +21,8 @@ struct Context {
     u32 *scratch = nullptr;           // device scratch for reductions (decompose / eval_at_point)
     size_t scratch_bytes = 0;
     int n_cus = 256;
+    u32 **coltab = nullptr;           // device: 2 pointer tables of coltab_cap entries each (fill_col_table)
+    size_t coltab_cap = 0;
     void *pinned = nullptr;           // page-locked host staging for small read-backs / uploads (kPinnedBytes)
 };
 constexpr size_t kPinnedBytes = 64 * 1024;
@@ -56,7 +58,14 @@ static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b -
 
 // by-value pointer tables passed as kernel arguments (no device-side pointer arrays to manage)
 constexpr int kMaxColsPerLaunch = 64;    // CFFT / bit-reverse batch chunk
-struct ColPtrs { u32 *p[kMaxColsPerLaunch]; };
+// Up to 64 columns travel by value in the kernel argument; more than that go through a pointer table in device memory
+// (`ext`), so that a batch of thousands of small columns is still ONE launch instead of one per 64 columns.
+struct ColPtrs { u32 *p[kMaxColsPerLaunch]; u32 *const *ext; };
+#ifdef __HIPCC__
+__device__ __forceinline__ u32 *colp(const ColPtrs &c, u32 i) { return c.ext ? c.ext[i] : c.p[i]; }   // i is workgroup-uniform: a scalar load
+#endif
+// Host: describe columns [0, n_cols) of `cols` in `out`; slot 0/1 = which of the two device tables to use when a launch needs two.
+int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot);
 constexpr int kMaxHashCols = 256;        // Merkle: columns absorbed per launch (multiple of 16)
 struct HashColPtrs { const u32 *p[kMaxHashCols]; };
 struct Soa4 { u32 *p[4]; };

@@ -76,6 +76,44 @@ int small_h2d(void *dev_dst, const void *host_src, size_t bytes) {
     TSTWO_HIP(hipStreamSynchronize(c.stream));
     return TSTWO_OK;
 }
+static std::vector<const u32 *> g_coltab_last[2];       // host copy of what each device table slot holds
+static u32 **g_coltab_last_base[2] = {nullptr, nullptr};
+static void coltab_cache_reset() { for (int i = 0; i < 2; i++) { g_coltab_last[i].clear(); g_coltab_last_base[i] = nullptr; } }
+
+int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot) {
+    Context &c = g_ctx;
+    out.ext = nullptr;
+    if (n_cols <= (size_t)kMaxColsPerLaunch) {
+        for (size_t i = 0; i < (size_t)kMaxColsPerLaunch; i++) out.p[i] = const_cast<u32 *>(cols[i < n_cols ? i : 0]);
+        return TSTWO_OK;
+    }
+    if (c.coltab_cap < n_cols) {
+        size_t cap = 1024;
+        while (cap < n_cols) cap *= 2;
+        if (c.coltab) {
+            TSTWO_HIP(hipStreamSynchronize(c.stream));
+            TSTWO_HIP(hipFree(c.coltab));
+            c.coltab = nullptr;
+            c.coltab_cap = 0;
+            coltab_cache_reset();
+        }
+        TSTWO_HIP(hipMalloc((void **)&c.coltab, 2 * cap * sizeof(u32 *)));
+        c.coltab_cap = cap;
+    }
+    u32 **dst = c.coltab + (size_t)(slot & 1) * c.coltab_cap;
+    // the passes of one transform ask for the same table again: skip the upload when the slot already holds it
+    std::vector<const u32 *> &lc = g_coltab_last[slot & 1];
+    u32 ***last_base = g_coltab_last_base;
+    if (!(last_base[slot & 1] == dst && lc.size() == n_cols && memcmp(lc.data(), cols, n_cols * sizeof(u32 *)) == 0)) {
+        int rc = small_h2d(dst, cols, n_cols * sizeof(u32 *));  // stream-ordered behind kernels still reading the table
+        if (rc) return rc;
+        lc.assign(cols, cols + n_cols);
+        last_base[slot & 1] = dst;
+    }
+    for (int i = 0; i < kMaxColsPerLaunch; i++) out.p[i] = nullptr;
+    out.ext = dst;
+    return TSTWO_OK;
+}
 int read_and_clear_flag(u32 *value) {
     Context &c = g_ctx;
     int rc = small_d2h(value, c.flag, sizeof(u32));
@@ -176,6 +214,8 @@ int tstwo_shutdown(void) {
     if (c.gen_pow2) (void)hipFree(c.gen_pow2);
     if (c.flag) (void)hipFree(c.flag);
     if (c.pinned) (void)hipHostFree(c.pinned);
+    if (c.coltab) (void)hipFree(c.coltab);
+    coltab_cache_reset();
     if (c.scratch) (void)hipFree(c.scratch);
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = Context();

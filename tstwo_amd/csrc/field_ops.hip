@@ -182,7 +182,7 @@ int finish_inverse() {
 // ---------------------------------------------------------------- bit reverse (backend/cpu/index.ts:62-79)
 // In-place swap of i <-> bitrev(i) for i < bitrev(i); one column per blockIdx.y.
 __global__ void __launch_bounds__(256) k_bit_reverse(ColPtrs cols, u32 log_n) {
-    u32 *v = cols.p[blockIdx.y];
+    u32 *v = colp(cols, blockIdx.y);
     size_t n = (size_t)1 << log_n;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_bit_reverse(ColPtrs cols, u32 log_n) {
 __global__ void __launch_bounds__(256) k_bit_reverse_tiled(ColPtrs cols, u32 log_n) {
     constexpr int T = 6, S = 1 << T, STRIDE = S + 1;
     __shared__ u32 lds[2][S * STRIDE];
-    u32 *__restrict__ v = cols.p[blockIdx.y];
+    u32 *__restrict__ v = colp(cols, blockIdx.y);
     const u32 mid_bits = log_n - 2 * T;
     const u32 m = blockIdx.x;
     const u32 rm = mid_bits ? (__brev(m) >> (32 - mid_bits)) : 0u;
@@ -349,12 +349,14 @@ int tstwo_bit_reverse(u32 *const *cols, size_t n_cols, size_t n) {
     while (((size_t)1 << log_n) < n) log_n++;
     if (log_n == 0 || n_cols == 0) return TSTWO_OK;
     TSTWO_REQUIRE_TABLE(cols, n_cols);
-    for (size_t base = 0; base < n_cols; base += kMaxColsPerLaunch) {
-        size_t cnt = n_cols - base < (size_t)kMaxColsPerLaunch ? n_cols - base : (size_t)kMaxColsPerLaunch;
+    const size_t kChunk = 32768;                       // gridDim.y limit; one launch for up to 32768 columns
+    for (size_t base = 0; base < n_cols; base += kChunk) {
+        const size_t cnt = n_cols - base < kChunk ? n_cols - base : kChunk;
         ColPtrs cp;
-        for (size_t i = 0; i < cnt; i++) cp.p[i] = cols[base + i];
+        int rc_tab = fill_col_table(cp, cols + base, cnt, 0);
+        if (rc_tab) return rc_tab;
         bool aligned = true;
-        for (size_t i = 0; i < cnt; i++) aligned = aligned && ((((uintptr_t)cp.p[i]) & 15) == 0);
+        for (size_t i = 0; i < cnt; i++) aligned = aligned && ((((uintptr_t)cols[base + i]) & 15) == 0);
         if (log_n >= 12 && log_n <= 40 && aligned) {
             hipLaunchKernelGGL(k_bit_reverse_tiled, dim3(1u << (log_n - 12), (unsigned)cnt), dim3(256), 0, ctx().stream, cp, log_n);
         } else {

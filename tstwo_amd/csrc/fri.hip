@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) k_fold_chunk_batch(ColPtrs cols, const qm
                                                          qm31 *__restrict__ partial_out, size_t out_stride, size_t n_out, int S, FoldFactors ff) {
     size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_out) return;
-    const u32 *__restrict__ coeffs = cols.p[blockIdx.y];
+    const u32 *__restrict__ coeffs = colp(cols, blockIdx.y);
     partial_in += (size_t)blockIdx.y * in_stride;
     partial_out += (size_t)blockIdx.y * out_stride;
     qm31 v[32];
@@ -422,6 +422,7 @@ int tstwo_eval_at_point_batch(const u32 *const *coeffs, size_t n_cols, u32 log_s
         int rc = ensure_scratch(2 * g * stride * sizeof(qm31));
         if (rc) return rc;
         ColPtrs cp;
+        cp.ext = nullptr;
         for (size_t i = 0; i < 64; i++) cp.p[i] = const_cast<u32 *>(coeffs[base + (i < g ? i : 0)]);
         qm31 *bufA = (qm31 *)c.scratch, *bufB = bufA + g * stride;
         u32 done = 0;
