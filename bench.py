@@ -167,9 +167,14 @@ def main():
     from tstwo_amd.backend import HipBackend, shard_columns
 
     L.init(dev_index)
+    side_stream = None
     if use_dist and backend_name == "nccl":
-        # share torch's current stream: copy-root -> all-gather -> next step are then stream-ordered, no host sync per step
-        L.call("tstwo_set_stream", C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        # One explicit stream shared by torch and the library: copy-root -> all-gather -> next step are then ordered on it,
+        # with no host sync per step.  (torch's default stream is the NULL stream; the library's own stream is non-blocking
+        # and does not synchronise with it, so the default stream must not be what RCCL orders against.)
+        side_stream = torch.cuda.Stream(device=dev_index)
+        torch.cuda.set_stream(side_stream)
+        L.call("tstwo_set_stream", C.c_void_p(side_stream.cuda_stream))
     backend = HipBackend()
 
     # ---- the rank's shard of the (world * n_cols) trace columns, resident in HBM
