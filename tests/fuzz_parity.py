@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (not collected by pytest; run on a GPU box: python tests/fuzz_parity.py --seconds 120).
+Random shapes for the CFFT entry points (in place, out of place, fused extension, many columns), Merkle trees of mixed sizes,
+folds, batch inverses, bit reversal and quotients; every result must equal the CPU oracle bit for bit."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import oracle as orc  # noqa: E402  (test infrastructure)
+from tstwo_amd import _lib as L  # noqa: E402
+import tstwo_amd as T  # noqa: E402
+from gpu_util import dev, host, p4, ptrs, vp  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=60)
+ap.add_argument("--seed", type=int, default=0)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+L.init(0)
+P = L.P
+half_odds = lambda lg: 1 << (31 - (lg + 2))
+_tw_cache = {}
+
+
+def twiddles(n):
+    if n not in _tw_cache:
+        tw, itw = L.DeviceBuffer(max(4 << max(n - 1, 0), 16)), L.DeviceBuffer(max(4 << max(n - 1, 0), 16))
+        L.call("tstwo_twiddles_build", half_odds(n - 1), n - 1, vp(tw), vp(itw))
+        _tw_cache[n] = (tw, itw, *orc.precompute_twiddles(half_odds(n - 1), n - 1))
+    return _tw_cache[n]
+
+
+def rcol(n):
+    return rng.integers(0, P, size=n, dtype=np.uint32)
+
+
+def case_cfft():
+    n = int(rng.integers(1, 17))
+    n_cols = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 64, 65, 100]))
+    if n >= 14:
+        n_cols = min(n_cols, 8)
+    tw, itw, otw, oitw = twiddles(n)
+    cols = [rcol(1 << n) for _ in range(n_cols)]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_cfft_evaluate", ptrs(d), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    pick = rng.choice(n_cols, size=min(3, n_cols), replace=False)
+    ev = {}
+    for c in pick:
+        ev[c] = host(d[c], 1 << n)
+        assert (ev[c] == orc.cfft_evaluate(cols[c], n, half_odds(n - 1), otw, n - 1)).all(), ("evaluate", n, n_cols, c)
+    out = [L.DeviceBuffer(4 << n) for _ in cols]
+    L.call("tstwo_cfft_interpolate_to", ptrs(d), ptrs(out), n_cols, n, half_odds(n - 1), vp(itw), n - 1)
+    for c in range(n_cols):
+        assert (host(out[c], 1 << n) == cols[c]).all(), ("interpolate_to", n, n_cols, c)
+    L.call("tstwo_cfft_interpolate", ptrs(d), n_cols, n, half_odds(n - 1), vp(itw), n - 1)
+    for c in pick:
+        assert (host(d[c], 1 << n) == cols[c]).all(), ("interpolate", n, n_cols, c)
+    return f"cfft n={n} cols={n_cols}"
+
+
+def case_extended():
+    n = int(rng.integers(3, 17))
+    ext = int(rng.integers(0, 4))
+    n_poly = max(n - ext, 1)
+    n_cols = int(rng.choice([1, 3, 9, 70]))
+    if n >= 14:
+        n_cols = min(n_cols, 4)
+    tw, _, otw, _ = twiddles(n)
+    polys = [rcol(1 << n_poly) for _ in range(n_cols)]
+    src = [dev(p) for p in polys]
+    out = [L.DeviceBuffer(4 << n) for _ in polys]
+    L.call("tstwo_cfft_evaluate_extended", ptrs(src), n_poly, ptrs(out), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    c = int(rng.integers(0, n_cols))
+    e = np.concatenate([polys[c], np.zeros((1 << n) - (1 << n_poly), dtype=np.uint32)])
+    assert (host(out[c], 1 << n) == orc.cfft_evaluate(e, n, half_odds(n - 1), otw, n - 1)).all(), ("extended", n_poly, n, n_cols)
+    return f"extended {n_poly}->{n} cols={n_cols}"
+
+
+def case_merkle():
+    k = int(rng.integers(1, 5))
+    logs = []
+    for _ in range(k):
+        logs += [int(rng.integers(0, 13))] * int(rng.choice([1, 2, 4, 7, 16, 20, 33]))
+    cols = [rcol(1 << lg) for lg in logs]
+    d = [dev(c) for c in cols]
+    mx = max(logs)
+    layers = L.DeviceBuffer(32 * ((2 << mx) - 1))
+    root = (C.c_uint8 * 32)()
+    L.call("tstwo_merkle_commit", ptrs(d), L.u32x(logs), len(logs), vp(layers), root)
+    olayers, oroot = orc.merkle_commit(cols, logs)
+    assert bytes(root) == oroot, ("merkle root", logs)
+    got = layers.download(np.uint8).reshape(-1, 32)
+    for lg in range(mx + 1):
+        assert (got[(1 << lg) - 1:(2 << lg) - 1] == olayers[lg]).all(), ("merkle layer", lg, logs)
+    return f"merkle {len(logs)} cols, max log {mx}"
+
+
+def case_fold():
+    n = int(rng.integers(3, 15))
+    src = [rcol(1 << n) for _ in range(4)]
+    dst = [rcol(1 << (n - 1)) for _ in range(4)]
+    alpha = tuple(int(x) for x in rng.integers(0, P, size=4))
+    _, itw, _, _ = twiddles(n)
+    ds, dd = [dev(c) for c in src], [dev(c) for c in dst]
+    L.call("tstwo_fri_fold_circle_into_line", p4(dd), 1 << (n - 1), p4(ds), n, vp(itw), n - 1, L.u32x(alpha))
+    exp = orc.fold_circle_into_line(dst, src, n, half_odds(n - 1), alpha)
+    for a, b in zip(dd, exp):
+        assert (host(a, 1 << (n - 1)) == b).all(), ("fold_circle", n)
+    out = [L.DeviceBuffer(max(4 << (n - 2), 16)) for _ in range(4)]
+    L.call("tstwo_fri_fold_line", p4(dd), n - 1, vp(itw), n - 1, L.u32x(alpha), p4(out))
+    exp2 = orc.fold_line(exp, n - 1, half_odds(n - 1), alpha)
+    for a, b in zip(out, exp2):
+        assert (host(a, 1 << (n - 2)) == b).all(), ("fold_line", n)
+    return f"folds n={n}"
+
+
+def case_fields():
+    n = int(rng.integers(1, 100000))
+    a = rng.integers(1, P, size=n, dtype=np.uint32)
+    da, do = dev(a), L.DeviceBuffer(4 * n + 16)
+    L.call("tstwo_m31_batch_inverse", vp(da), vp(do), n)
+    assert (host(do, n) == orc.m31_batch_inverse(a)).all(), ("m31 inverse", n)
+    lg = int(rng.integers(1, 17))
+    b = rcol(1 << lg)
+    db = dev(b)
+    L.call("tstwo_bit_reverse", ptrs([db]), 1, 1 << lg)
+    assert (host(db, 1 << lg) == orc.bit_reverse(b)).all(), ("bit reverse", lg)
+    return f"fields n={n} bitrev log={lg}"
+
+
+cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields]
+t0, done = time.time(), 0
+while time.time() - t0 < args.seconds:
+    msg = cases[done % len(cases)]()
+    done += 1
+    if done % 501 == 0:
+        print(f"[{time.time() - t0:6.1f}s] {done} cases ok (last: {msg})", flush=True)
+print(f"fuzz ok: {done} cases in {time.time() - t0:.1f}s, seed {args.seed}")
