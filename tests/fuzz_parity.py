@@ -135,7 +135,65 @@ def case_fields():
     return f"fields n={n} bitrev log={lg}"
 
 
-cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields]
+def _low_degree_secure(log_deg, blow):
+    domain = T.CanonicCoset(log_deg + blow).circleDomain()
+    polys = [T.HipCirclePoly(rcol(1 << log_deg)) for _ in range(4)]
+    return domain, polys
+
+
+def case_fri():
+    """commit (device transcript) == commit (host transcript); decommit; host verifier accepts."""
+    blow = int(rng.integers(1, 4))
+    n_cols = int(rng.integers(1, 4))
+    degs = sorted(rng.choice(np.arange(3, 12), size=n_cols, replace=False).tolist(), reverse=True)
+    last = int(rng.integers(0, min(degs) - 1)) if min(degs) > 1 else 0
+    cfg = T.FriConfig(last, blow, int(rng.integers(1, 12)))
+    tw = T.precompute_twiddles(T.CanonicCoset(degs[0] + blow).circleDomain().halfCoset)
+    cols = []
+    for dg in degs:
+        domain, polys = _low_degree_secure(dg, blow)
+        evs = T.evaluate_polynomials(polys, domain, tw)
+        cols.append(T.SecureEvaluation(domain, T.SecureColumnByCoords([e.values for e in evs])))
+    ch_d, ch_h = T.Blake2sChannel(), T.Blake2sChannel()
+    pd = T.FriProver.commit(ch_d, cfg, cols, tw, device_channel=True)
+    ph = T.FriProver.commit(ch_h, cfg, cols, tw, device_channel=False)
+    assert ch_d.digest() == ch_h.digest(), ("fri transcript", degs, blow, last)
+    assert [l.merkle_tree.root() for l in pd.inner_layers] == [l.merkle_tree.root() for l in ph.inner_layers]
+    proof, positions = pd.decommit(ch_d)
+    vch = T.Blake2sChannel()
+    v = T.FriVerifier.commit(vch, cfg, proof, [T.CirclePolyDegreeBound(dg) for dg in degs])
+    assert v.sample_query_positions(vch) == positions
+    v.decommit([c.values.gather(positions[c.domain.logSize()]) for c in cols])
+    return f"fri degs={degs} blow={blow} last={last}"
+
+
+def case_pcs():
+    blow = int(rng.integers(1, 3))
+    config = T.PcsConfig(pow_bits=int(rng.integers(0, 10)), fri_config=T.FriConfig(int(rng.integers(0, 3)), blow, int(rng.integers(1, 8))))
+    trees = [[int(rng.integers(4, 11)) for _ in range(int(rng.integers(1, 5)))] for _ in range(int(rng.integers(1, 3)))]
+    mx = max(lg for t in trees for lg in t)
+    tw = T.precompute_twiddles(T.CanonicCoset(mx + blow).circleDomain().halfCoset)
+    scheme = T.CommitmentSchemeProver(config, tw)
+    ch = T.Blake2sChannel()
+    config.mix_into(ch)
+    for logs in trees:
+        tb = scheme.tree_builder()
+        tb.extend_evals([T.HipCircleEvaluation(T.CanonicCoset(lg).circleDomain(), rcol(1 << lg)) for lg in logs])
+        tb.commit(ch)
+    pt = T.CirclePoint.get_random_point(ch)
+    pts = [[[pt] for _ in logs] for logs in trees]
+    proof = scheme.prove_values(pts, ch)
+    ver = T.CommitmentSchemeVerifier(config)
+    vch = T.Blake2sChannel()
+    config.mix_into(vch)
+    for logs, root in zip(trees, proof.commitments):
+        ver.commit(root, logs, vch)
+    vpt = T.CirclePoint.get_random_point(vch)
+    ver.verify_values([[[vpt] for _ in logs] for logs in trees], proof, vch)
+    return f"pcs trees={trees} blow={blow}"
+
+
+cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs]
 t0, done = time.time(), 0
 while time.time() - t0 < args.seconds:
     msg = cases[done % len(cases)]()

@@ -1096,3 +1096,17 @@ def test_bit_reverse_back_and_coset_sub_evaluation():
     sub = ev.coset_sub_evaluation(5, 3)
     assert sub.at(0).value == vals[5] and sub.get(30).value == vals[(5 + 90) & 63]
     assert [m.value for m in sub.gather(range(40))] == [int(vals[(5 + 3 * i) & 63]) for i in range(40)]
+
+
+def test_pcs_trees_of_different_heights():
+    """Regression (found by tests/fuzz_parity.py): every tree is handed the query positions of all column sizes; a tree lower
+    than the tallest one must ignore the sizes it does not have (pcs/prover.ts Rust text :137-141)."""
+    config = T.PcsConfig(pow_bits=3, fri_config=T.FriConfig(1, 1, 5))
+    logs = [[9, 7], [5, 6]]                       # the second tree is lower than the first
+    scheme, ch = _pcs_setup(config, logs, seed=34000)
+    point = T.CirclePoint.get_random_point(ch)
+    pts = [[[point], [point]], [[point], [point]]]
+    proof = scheme.prove_values(pts, ch)
+    verifier, vch = _pcs_verifier(config, logs, proof.commitments)
+    T.CirclePoint.get_random_point(vch)
+    verifier.verify_values(pts, proof, vch)

@@ -86,10 +86,9 @@ class MerkleProver:
         `_decommit_walk` below is the same walk on the host mirror, kept for cross-checking."""
         cols = list(columns)
         max_log = len(self.layers) - 1
-        sets = [(lg, list(q)) for lg, q in queriesPerLogSize.items() if q]
-        for lg, _ in sets:
-            if lg > max_log or lg < 0:
-                raise ValueError("query log size outside the tree")
+        # like the reference, only the entries for layers this tree has are looked at (a commitment scheme hands every tree the
+        # query positions of ALL column sizes, pcs/prover.ts Rust text :137-141)
+        sets = [(lg, list(q)) for lg, q in queriesPerLogSize.items() if q and 0 <= lg <= max_log]
         total_q = sum(len(q) for _, q in sets)
         cap_v = max(1, total_q * max(1, len(cols)))
         cap_h = max(1, 2 * total_q * (max_log + 1))
