@@ -193,7 +193,101 @@ def case_pcs():
     return f"pcs trees={trees} blow={blow}"
 
 
-cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs]
+def _rq():
+    return tuple(int(x) for x in rng.integers(0, P, size=4))
+
+
+def _rand_secure_point():
+    """a random point of the QM31 circle: k * SECURE_FIELD_CIRCLE_GEN for a random k"""
+    k = int(rng.integers(1, 1 << 30))
+    return T.SECURE_FIELD_CIRCLE_GEN.mul(k, T.QM31.one(), T.QM31.zero())
+
+
+def case_quotients():
+    """accumulateQuotients through the host mirror (quotientConstants + kernel) == the oracle's per-row reference formulation."""
+    n = int(rng.integers(1, 13))
+    n_cols = int(rng.integers(1, 9))
+    cols = [rcol(1 << n) for _ in range(n_cols)]
+    n_batches = int(rng.integers(1, 4))
+    batches_o, batches_t = [], []
+    for _ in range(n_batches):
+        pt = _rand_secure_point()
+        cv = [(int(c), _rq()) for c in rng.choice(n_cols, size=int(rng.integers(1, n_cols + 1)), replace=False)]
+        batches_o.append((pt.x.tup(), pt.y.tup(), cv))
+        batches_t.append(T.ColumnSampleBatch(pt, [(c, T.QM31.from_u32_unchecked(*v)) for c, v in cv]))
+    coeff = _rq()
+    domain = T.CanonicCoset(n).circleDomain()
+    got = T.accumulateQuotients(domain, [T.HipColumn(c) for c in cols], T.QM31.from_u32_unchecked(*coeff), batches_t).values.to_numpy()
+    exp = orc.accumulate_quotients(half_odds(n - 1), n, cols, coeff, batches_o)
+    for k in range(4):
+        assert (got[k] == exp[k]).all(), ("quotients", n, n_cols, n_batches)
+    return f"quotients n={n} cols={n_cols} batches={n_batches}"
+
+
+def case_eval_decommit_qm31():
+    n = int(rng.integers(1, 15))
+    n_cols = int(rng.choice([1, 2, 5, 70]))
+    cols = [rcol(1 << n) for _ in range(n_cols)]
+    pt = _rand_secure_point()
+    got = T.HipCirclePoly.eval_at_point_batch([T.HipCirclePoly(c) for c in cols], pt)
+    c = int(rng.integers(0, n_cols))
+    assert got[c].tup() == tuple(orc.eval_at_point(cols[c], n, pt.x.tup(), pt.y.tup())), ("eval_at_point", n, n_cols)
+    # Merkle decommit: in-library walk == host walk, verifier accepts
+    logs = sorted([int(rng.integers(0, 11)) for _ in range(int(rng.integers(1, 7)))], reverse=True)
+    hc = [T.HipColumn(rcol(1 << lg)) for lg in logs]
+    tree = T.MerkleProver.commit(hc)
+    queries = {lg: sorted(set(int(x) for x in rng.integers(0, 1 << lg, size=int(rng.integers(1, 6))))) for lg in set(logs) if rng.random() < 0.8}
+    if not queries:
+        queries = {logs[0]: [0]}
+    v1, d1 = tree.decommit(queries, hc)
+    v2, d2 = tree._decommit_walk(queries, hc)
+    assert [v.value for v in v1] == [v.value for v in v2] and d1.hashWitness == d2.hashWitness
+    assert [v.value for v in d1.columnWitness] == [v.value for v in d2.columnWitness]
+    T.MerkleVerifier(T.Blake2sMerkleHasher, tree.root(), logs).verify(queries, v1, d1)
+    # QM31 column mul / batch inverse vs oracle
+    m = int(rng.integers(1, 5000))
+    a4 = [rng.integers(1, P, size=m, dtype=np.uint32) for _ in range(4)]
+    b4 = [rcol(m) for _ in range(4)]
+    A, B = T.SecureColumnByCoords.from_numpy(a4), T.SecureColumnByCoords.from_numpy(b4)
+    be = T.HipBackend()
+    for g, e in zip(be.secureMul(A, B).to_numpy(), orc.qm31_col_mul(a4, b4)):
+        assert (g == e).all(), ("qm31 mul", m)
+    for g, e in zip(be.batchInverse(A).to_numpy(), orc.qm31_batch_inverse(a4)):
+        assert (g == e).all(), ("qm31 inverse", m)
+    return f"eval/decommit/qm31 n={n} cols={n_cols} tree={logs}"
+
+
+def case_rows_sharded():
+    """virtual ranks: row-sharded folds and subtree roots == whole-layer results"""
+    from tstwo_amd import distributed as D
+    n = int(rng.integers(6, 13))
+    world = int(rng.choice([2, 4, 8]))
+    if (1 << (n - 2)) // world < 4:
+        world = 2
+    domain = T.CanonicCoset(n).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    src_np, dst_np = [rcol(1 << n) for _ in range(4)], [rcol(1 << (n - 1)) for _ in range(4)]
+    alpha = T.QM31.from_u32_unchecked(*_rq())
+    src = T.SecureEvaluation(domain, T.SecureColumnByCoords.from_numpy(src_np))
+    dst = T.LineEvaluation(T.LineDomain(domain.halfCoset), T.SecureColumnByCoords.from_numpy(dst_np))
+    T.fold_circle_into_line(dst, src, alpha, tw)
+    whole = dst.values.to_numpy()
+    root = T.MerkleProver.commit(dst.values.columns).root()
+    parts, subroots = [], []
+    for rank in range(world):
+        s_, c_ = D.shard_rows(1 << (n - 1), world, rank)
+        d = T.SecureColumnByCoords.from_numpy([x[s_:s_ + c_] for x in dst_np])
+        D.fold_circle_into_line_rows(d, T.SecureColumnByCoords.from_numpy([x[2 * s_:2 * (s_ + c_)] for x in src_np]), n, rank, world, alpha, tw)
+        parts.append(d.to_numpy())
+        subroots.append(T.MerkleProver.commit(d.columns).root())
+    for k in range(4):
+        assert (np.concatenate([p[k] for p in parts]) == whole[k]).all(), ("rows fold", n, world)
+    assert D.combine_subtree_roots(subroots) == root, ("rows root", n, world)
+    return f"rows n={n} world={world}"
+
+
+cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs, case_quotients, case_eval_decommit_qm31,
+         case_rows_sharded]
 t0, done = time.time(), 0
 while time.time() - t0 < args.seconds:
     msg = cases[done % len(cases)]()

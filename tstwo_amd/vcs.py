@@ -283,5 +283,7 @@ class MerkleVerifier:
             raise ValueError("too many Queried values")
         if ci != len(decommitment.columnWitness):
             raise ValueError("Witness is too long.")
+        if not last:            # no query reached the root (the reference dereferences lastLayerHashes[0] and throws, verifier.ts:128)
+            raise ValueError("no queried node: nothing to verify")
         if last[0][1] != self.root:
             raise ValueError("Root mismatch.")
