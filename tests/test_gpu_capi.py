@@ -202,7 +202,7 @@ def test_cfft_bigger_tree_and_errors():
         L.call("tstwo_cfft_evaluate", ptrs(d), 1, n, half_odds(n - 1), vp(small), 3)
 
 
-@pytest.mark.parametrize("n", [18, 20, 22, 23, 24])
+@pytest.mark.parametrize("n", [17, 18, 19, 20, 21, 22, 23, 24])
 def test_cfft_large_properties(n):
     """BASELINE sizes: round trip, agreement with eval_at_point at sampled domain points (the reference's
     property test), linearity, and oracle equality on one column."""
@@ -503,7 +503,7 @@ def test_cfft_interpolate_to_matches_in_place(n):
     assert (dst[0].download() == evals[0]).all()
 
 
-@pytest.mark.parametrize("n", [26, 28])
+@pytest.mark.parametrize("n", [25, 26, 27, 28])
 def test_cfft_maximum_sizes(n):
     """The largest transforms the tiled path plans (3 passes at log 26, 3 at log 28; 1 GiB column at log 28): the
     evaluation agrees with eval_at_point at sampled domain points and interpolate inverts it."""
