@@ -21,6 +21,7 @@ from gpu_util import dev, host, p4, ptrs, vp  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=60)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--big", action="store_true", help="only the large-size cases (tiled CFFT path, 13 <= log <= 22)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 L.init(0)
@@ -286,12 +287,59 @@ def case_rows_sharded():
     return f"rows n={n} world={world}"
 
 
+def case_cfft_big():
+    """tiled path: random log 13..22 and column counts; oracle on one column up to log 18, round trips and the fused
+    extension against extend + evaluate (GPU vs GPU) beyond."""
+    n = int(rng.integers(13, 23))
+    max_cols = max(1, min(40, (1 << 25) >> n))
+    n_cols = int(rng.integers(1, max_cols + 1))
+    tw, itw, otw, oitw = twiddles(n)
+    cols = [rcol(1 << n) for _ in range(n_cols)]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_cfft_evaluate", ptrs(d), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    c = int(rng.integers(0, n_cols))
+    if n <= 18:
+        assert (host(d[c], 1 << n) == orc.cfft_evaluate(cols[c], n, half_odds(n - 1), otw, n - 1)).all(), ("big evaluate", n, n_cols, c)
+    out = [L.DeviceBuffer(4 << n) for _ in cols]
+    L.call("tstwo_cfft_interpolate_to", ptrs(d), ptrs(out), n_cols, n, half_odds(n - 1), vp(itw), n - 1)
+    for k in range(n_cols):
+        assert (host(out[k], 1 << n) == cols[k]).all(), ("big roundtrip", n, n_cols, k)
+    ext = int(rng.integers(1, 3))
+    polys = [dev(col[:1 << (n - ext)]) for col in cols]
+    L.call("tstwo_cfft_evaluate_extended", ptrs(polys), n - ext, ptrs(out), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    ref = [L.DeviceBuffer(4 << n) for _ in cols]
+    for p_, r in zip(polys, ref):
+        L.call("tstwo_poly_extend", vp(p_), n - ext, vp(r), n)
+    L.call("tstwo_cfft_evaluate", ptrs(ref), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    for k in range(n_cols):
+        assert (host(out[k], 1 << n) == host(ref[k], 1 << n)).all(), ("big extended", n, ext, n_cols, k)
+    return f"cfft_big n={n} cols={n_cols} ext={ext}"
+
+
+def case_merkle_big():
+    logs = []
+    for _ in range(int(rng.integers(1, 4))):
+        logs += [int(rng.integers(10, 19))] * int(rng.choice([1, 4, 16, 20, 32]))
+    while sum(1 << lg for lg in logs) > (1 << 24):
+        logs.pop()
+    cols = [rcol(1 << lg) for lg in logs]
+    d = [dev(c) for c in cols]
+    mx = max(logs)
+    layers = L.DeviceBuffer(32 * ((2 << mx) - 1))
+    root = (C.c_uint8 * 32)()
+    L.call("tstwo_merkle_commit", ptrs(d), L.u32x(logs), len(logs), vp(layers), root)
+    assert bytes(root) == orc.merkle_commit(cols, logs)[1], ("merkle big", logs)
+    return f"merkle_big {len(logs)} cols max log {mx}"
+
+
 cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs, case_quotients, case_eval_decommit_qm31,
          case_rows_sharded]
+if args.big:
+    cases = [case_cfft_big, case_merkle_big]
 t0, done = time.time(), 0
 while time.time() - t0 < args.seconds:
     msg = cases[done % len(cases)]()
     done += 1
-    if done % 501 == 0:
+    if done % (7 if args.big else 501) == 0:
         print(f"[{time.time() - t0:6.1f}s] {done} cases ok (last: {msg})", flush=True)
 print(f"fuzz ok: {done} cases in {time.time() - t0:.1f}s, seed {args.seed}")
