@@ -56,6 +56,15 @@ int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);     /* sync
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
 int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes);        /* async d2d */
 int tstwo_zero(void *dev, size_t bytes);                                  /* async; Column.zeros, backend/index.ts:56 */
+/* hipGraph capture of a launch sequence (launch-bound loops: e.g. the 20+ small kernels of a FRI commit with the device
+ * channel).  Between begin and end every asynchronous entry point is RECORDED on the library's stream instead of executed;
+ * tstwo_graph_launch replays the recorded sequence with one call.  Rules while capturing: no entry point that returns data
+ * to the host (they synchronise); allocations must hit the library's caching allocator (run the sequence once eagerly
+ * first); all buffers the sequence uses must outlive the graph, which addresses them by value. */
+int tstwo_graph_begin_capture(void);
+int tstwo_graph_end_capture(void **graph_exec);
+int tstwo_graph_launch(void *graph_exec);
+int tstwo_graph_destroy(void *graph_exec);
 /* HIP events on the library's stream (bench.py times kernels with these) */
 int tstwo_event_create(void **ev);
 int tstwo_event_record(void *ev);

@@ -1110,3 +1110,30 @@ def test_pcs_trees_of_different_heights():
     verifier, vch = _pcs_verifier(config, logs, proof.commitments)
     T.CirclePoint.get_random_point(vch)
     verifier.verify_values(pts, proof, vch)
+
+
+def test_fri_commit_plan_graph_replay_equals_eager():
+    """hipGraph capture of the device-transcript commit loop (FriCommitPlan): replaying the graph on new data written into the
+    same input buffers gives the eager commit's roots, last layer and channel state — twice, with different data."""
+    LOGD, BLOW = 8, 2
+    cfg = T.FriConfig(1, BLOW, 5)
+    col, tw = _secure_low_degree_eval(LOGD, BLOW, 35000)
+    plan = T.FriCommitPlan(cfg, [col], tw)
+    for seed in (35100, 35200):
+        fresh, _ = _secure_low_degree_eval(LOGD, BLOW, seed)
+        for dst, src in zip(col.values.columns, fresh.values.columns):          # new evaluations into the plan's input buffers
+            L.call("tstwo_copy", C.c_void_p(dst.ptr), C.c_void_p(src.ptr), 4 * dst.len())
+        ch_g, ch_e = T.Blake2sChannel(), T.Blake2sChannel()
+        ch_g.mix_u64(seed); ch_e.mix_u64(seed)
+        pg = plan.run(ch_g)
+        pe = T.FriProver.commit(ch_e, cfg, [fresh], tw)
+        assert pg.first_layer.merkle_tree.root() == pe.first_layer.merkle_tree.root()
+        assert [l.merkle_tree.root() for l in pg.inner_layers] == [l.merkle_tree.root() for l in pe.inner_layers]
+        assert [c.tup() for c in pg.last_layer_poly.coeffs] == [c.tup() for c in pe.last_layer_poly.coeffs]
+        assert ch_g.digest() == ch_e.digest()
+        proof, positions = pg.decommit(ch_g)
+        _fri_verify_with_channel = T.FriVerifier.commit
+        vch = T.Blake2sChannel(); vch.mix_u64(seed)
+        v = T.FriVerifier.commit(vch, cfg, proof, [T.CirclePolyDegreeBound(LOGD)])
+        assert v.sample_query_positions(vch) == positions
+        v.decommit(_query_evals([col], positions))

@@ -17,6 +17,10 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_set_stream: { args: [u64], returns: i32 },
   tstwo_sync: { args: [], returns: i32 },
   tstwo_trim: { args: [], returns: i32 },
+  tstwo_graph_begin_capture: { args: [], returns: i32 },
+  tstwo_graph_end_capture: { args: [P], returns: i32 },
+  tstwo_graph_launch: { args: [u64], returns: i32 },
+  tstwo_graph_destroy: { args: [u64], returns: i32 },
   tstwo_event_create: { args: [P], returns: i32 },
   tstwo_event_record: { args: [u64], returns: i32 },
   tstwo_event_elapsed_ms: { args: [u64, u64, P], returns: i32 },

@@ -10,7 +10,7 @@ from .channel import Blake2sChannel, DeviceChannel, HipGrindOps, grind  # noqa: 
 from .circle import (CanonicCoset, CircleDomain, CirclePoint, CirclePointIndex, Coset, LineDomain,  # noqa: F401
                      M31_CIRCLE_GEN, SECURE_FIELD_CIRCLE_GEN, bit_reverse_index)
 from .fields import CM31, M31, P, QM31  # noqa: F401
-from .fri_prover import (FriConfig, FriLayerProof, FriProof, FriProver, LinePoly, line_interpolate,  # noqa: F401
+from .fri_prover import (FriCommitPlan, FriConfig, FriLayerProof, FriProof, FriProver, LinePoly, line_interpolate,  # noqa: F401
                          compute_decommitment_positions_and_witness_evals)
 from .fri_verifier import (CirclePolyDegreeBound, FriVerificationError, FriVerifier, LinePolyDegreeBound,  # noqa: F401
                            SparseEvaluation, accumulate_line, compute_decommitment_positions_and_rebuild_evals)

@@ -43,6 +43,10 @@ _SIGS = {
     "tstwo_download": [vp, vp, C.c_size_t],
     "tstwo_copy": [vp, vp, C.c_size_t],
     "tstwo_zero": [vp, C.c_size_t],
+    "tstwo_graph_begin_capture": [],
+    "tstwo_graph_end_capture": [C.POINTER(vp)],
+    "tstwo_graph_launch": [vp],
+    "tstwo_graph_destroy": [vp],
     "tstwo_event_create": [C.POINTER(vp)],
     "tstwo_event_record": [vp],
     "tstwo_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],

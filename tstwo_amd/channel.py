@@ -103,14 +103,17 @@ class DeviceChannel:
     """The channel's state (digest, n_challenges, n_sent) mirrored in 40 bytes of device memory, so that a launch sequence
     (FRI commit: tree -> mix_root -> draw_felt -> fold -> tree ...) never waits for the host.  Rust draw semantics only."""
 
-    def __init__(self, host: Blake2sChannel):
-        import numpy as np
-
+    def __init__(self, host: Blake2sChannel, buf=None):
         from . import _lib as L
+        self.buf = buf if buf is not None else L.DeviceBuffer(64)
+        self.load(host)
+
+    def load(self, host: Blake2sChannel) -> None:
+        """(Re)start from the host channel's state (one 64-byte upload)."""
+        import numpy as np
         if host.ts_compat:
             raise ValueError("the device channel implements the Rust draw semantics only")
         self.host = host
-        self.buf = L.DeviceBuffer(64)
         st = np.zeros(16, dtype=np.uint32)
         st[:8] = np.frombuffer(host.digest(), dtype="<u4")
         st[8], st[9] = host.n_challenges, host.n_sent

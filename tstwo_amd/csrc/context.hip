@@ -237,6 +237,42 @@ int tstwo_set_stream(void *hip_stream) {
     return TSTWO_OK;
 }
 
+// ---- hipGraph capture of a launch sequence on the library's stream (launch-bound loops such as the small layers of a FRI
+// commit): everything enqueued between begin and end is recorded instead of executed; the instantiated graph replays the
+// whole sequence with one call.  Only asynchronous entry points may be called while capturing (anything that reads back to
+// the host synchronises and fails the capture); allocations must be served by the caching allocator (warm it with one eager
+// run of the same sequence) and every buffer the sequence touches must stay alive as long as the graph is replayed.
+int tstwo_graph_begin_capture(void) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_HIP(hipStreamBeginCapture(g_ctx.stream, hipStreamCaptureModeRelaxed));
+    return TSTWO_OK;
+}
+int tstwo_graph_end_capture(void **graph_exec) {
+    TSTWO_REQUIRE_READY();
+    if (!graph_exec) return set_error(TSTWO_ERR_BAD_ARG, "graph: null out pointer");
+    *graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    TSTWO_HIP(hipStreamEndCapture(g_ctx.stream, &graph));
+    if (!graph) return set_error(TSTWO_ERR_HIP, "graph: capture produced no graph");
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+    *graph_exec = (void *)exec;
+    return TSTWO_OK;
+}
+int tstwo_graph_launch(void *graph_exec) {
+    TSTWO_REQUIRE_READY();
+    if (!graph_exec) return set_error(TSTWO_ERR_BAD_ARG, "graph: null handle");
+    TSTWO_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, g_ctx.stream));
+    return TSTWO_OK;
+}
+int tstwo_graph_destroy(void *graph_exec) {
+    if (!graph_exec) return TSTWO_OK;
+    TSTWO_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return TSTWO_OK;
+}
+
 int tstwo_sync(void) {
     TSTWO_REQUIRE_READY();
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));

@@ -205,6 +205,38 @@ class FriInnerLayerProver:
 FriLayer = FriInnerLayerProver
 
 
+class _HostTranscript:
+    """mix_root / draw_felt on the host channel: one 32-byte root read-back per layer."""
+    sync_root = True
+
+    def __init__(self, channel):
+        self.channel = channel
+
+    def mix_and_draw(self, tree):
+        self.channel.mix_root(tree.root())
+        return self.channel.draw_felt()
+
+    fold_line = staticmethod(HipFriOps.fold_line)
+    fold_circle = staticmethod(HipFriOps.fold_circle_into_line)
+
+
+class _DeviceTranscript:
+    """mix_root / draw_felt by the device channel: alpha k lands in slot k of `alphas`; nothing is read back."""
+    sync_root = False
+
+    def __init__(self, dch: DeviceChannel, alphas):
+        self.dch, self.alphas, self.k = dch, alphas, 0
+
+    def mix_and_draw(self, tree) -> int:
+        ptr = self.alphas.ptr + 16 * self.k
+        self.k += 1
+        self.dch.mix_root_draw_felt(tree.root_ptr(), ptr)
+        return ptr
+
+    fold_line = staticmethod(HipFriOps.fold_line_dev)
+    fold_circle = staticmethod(HipFriOps.fold_circle_into_line_dev)
+
+
 class FriProver:
     def __init__(self, config, first_layer, inner_layers, last_layer_coeffs):
         self.config, self.first_layer, self.inner_layers, self.last_layer_poly = config, first_layer, inner_layers, last_layer_coeffs
@@ -222,53 +254,56 @@ class FriProver:
         # Device transcript: when every fold can take its twiddles from the tree and the channel has Rust semantics, the whole
         # commit loop is one launch sequence — roots are mixed and alphas drawn by the device channel, nothing is read back
         # until the last layer.  Otherwise: the host channel, one 32-byte read-back per layer.
+        on_device = (device_channel and not getattr(channel, "ts_compat", False) and hasattr(channel, "_digest")
+                     and FriProver._device_capable(columns, twiddles))
+        if on_device:
+            dch = DeviceChannel(channel)
+            alphas = L.DeviceBuffer(16 * (columns[0].domain.logSize() + 2))
+            first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _DeviceTranscript(dch, alphas))
+            dch.sync_to_host()                                               # the host channel continues from the device state
+        else:
+            first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _HostTranscript(channel))
+        last = FriProver._commit_last_layer(channel, config, layer_eval, twiddles)
+        return FriProver(config, first_layer, inner, last)
+
+    @staticmethod
+    def _device_capable(columns, twiddles) -> bool:
+        first_log = (columns[0].domain.size() >> CIRCLE_TO_LINE_FOLD_STEP).bit_length() - 1
+        return (all(HipFriOps.can_fold_on_device(c.domain, twiddles) for c in columns)
+                and HipFriOps.can_fold_on_device(LineDomain(Coset.half_odds(first_log)), twiddles))
+
+    @staticmethod
+    def _commit_layers(config: FriConfig, columns, twiddles: TwiddleTree, transcript) -> tuple:
+        """commitInnerLayers (fri.ts:676-716) with the Merkle / channel wiring of Rust.  `transcript` mixes a tree's root and
+        draws alpha (host or device).  With the device transcript this only ENQUEUES work (capturable into a hipGraph)."""
         folded = lambda v: v.domain.size() >> CIRCLE_TO_LINE_FOLD_STEP
         first_log = (folded(columns[0])).bit_length() - 1
-        on_device = (device_channel and not getattr(channel, "ts_compat", False) and hasattr(channel, "_digest")
-                     and all(HipFriOps.can_fold_on_device(c.domain, twiddles) for c in columns)
-                     and HipFriOps.can_fold_on_device(LineDomain(Coset.half_odds(first_log)), twiddles))
-        dch = DeviceChannel(channel) if on_device else None
-        alphas = L.DeviceBuffer(16 * (first_log + 2)) if on_device else None
-        n_alpha = [0]
-
-        def mix_and_draw(tree):
-            """mix_root(tree.root()) then draw_felt(); returns alpha as a QM31 (host path) or a device address (device path)."""
-            if on_device:
-                ptr = alphas.ptr + 16 * n_alpha[0]
-                n_alpha[0] += 1
-                dch.mix_root_draw_felt(tree.root_ptr(), ptr)
-                return ptr
-            channel.mix_root(tree.root())
-            return channel.draw_felt()
-
-        fold_line_ = HipFriOps.fold_line_dev if on_device else HipFriOps.fold_line
-        fold_circle_ = HipFriOps.fold_circle_into_line_dev if on_device else HipFriOps.fold_circle_into_line
-
         # first layer: one tree over every column's coordinate columns (Rust FriFirstLayerProver::new), root -> channel
         coord_cols = [cc for c in columns for cc in c.values.columns]
-        first_tree = MerkleProver.commit(coord_cols, sync_root=not on_device)
-        alpha = mix_and_draw(first_tree)
+        first_tree = MerkleProver.commit(coord_cols, sync_root=transcript.sync_root)
+        alpha = transcript.mix_and_draw(first_tree)
         first_layer = FriFirstLayerProver(columns, first_tree)
-
         layer_eval = LineEvaluation.new_zero(LineDomain(Coset.half_odds(first_log)))
         it = iter(columns)
-        fold_circle_(layer_eval, next(it), alpha, twiddles)
+        transcript.fold_circle(layer_eval, next(it), alpha, twiddles)
         nxt = next(it, None)
         inner = []
         while layer_eval.len() > config.last_layer_domain_size():
-            tree = MerkleProver.commit(layer_eval.values.columns, sync_root=not on_device)      # FriInnerLayerProver::new
-            alpha = mix_and_draw(tree)
+            tree = MerkleProver.commit(layer_eval.values.columns, sync_root=transcript.sync_root)      # FriInnerLayerProver::new
+            alpha = transcript.mix_and_draw(tree)
             layer = FriInnerLayerProver(layer_eval, tree)
-            layer_eval = fold_line_(layer_eval, alpha, twiddles)
+            layer_eval = transcript.fold_line(layer_eval, alpha, twiddles)
             if nxt is not None and folded(nxt) == layer_eval.len():
-                fold_circle_(layer_eval, nxt, alpha, twiddles)
+                transcript.fold_circle(layer_eval, nxt, alpha, twiddles)
                 nxt = next(it, None)
             inner.append(layer)
         if nxt is not None:
             raise ValueError("not all columns were consumed")                # Rust: assert!(columns.is_empty())
-        if on_device:
-            dch.sync_to_host()                                               # the host channel continues from the device state
-        # last layer (fri.ts:718-754)
+        return first_layer, inner, layer_eval
+
+    @staticmethod
+    def _commit_last_layer(channel, config: FriConfig, layer_eval: LineEvaluation, twiddles: TwiddleTree) -> LinePoly:
+        """commitLastLayer (fri.ts:718-754)."""
         if layer_eval.len() != config.last_layer_domain_size():
             raise ValueError("last layer domain size mismatch")
         coeffs_br = line_interpolate(layer_eval, twiddles)
@@ -279,7 +314,7 @@ class FriProver:
             raise ValueError("invalid degree")
         last = LinePoly.from_ordered_coefficients(ordered[:bound])
         channel.mix_felts(last.coeffs)          # Rust: channel.mix_felts(&last_layer_poly) = its bit-reversed coefficient slice
-        return FriProver(config, first_layer, inner, last)
+        return last
 
     def decommit(self, channel) -> tuple:
         """fri.ts:759-766: draws the queries, returns (FriProof, query positions by column log size)."""
@@ -299,3 +334,53 @@ class FriProver:
         return FriProof(first, inner, self.last_layer_poly)
 
     decommitOnQueries = decommit_on_queries
+
+
+class FriCommitPlan:
+    """A FRI commit of FIXED shape captured once into a hipGraph (tstwo_graph_*): the 4-6 small launches per layer of the
+    device-transcript commit loop are launch-bound below ~2^16 rows, so replaying them as one graph removes the host from
+    the loop entirely.  The plan owns every buffer the sequence touches; `columns` are the INPUT buffers — write new
+    evaluations into them (same shape) and call run() again.  The FriProver returned by run() views the plan's buffers and
+    is valid until the next run()."""
+
+    def __init__(self, config: FriConfig, columns, twiddles: TwiddleTree):
+        import ctypes as C
+        if not columns or not all(c.domain.isCanonic() for c in columns):
+            raise ValueError("no columns" if not columns else "not canonic")
+        if not FriProver._device_capable(columns, twiddles):
+            raise ValueError("twiddle tree mismatch")
+        self.config, self.columns, self.twiddles = config, list(columns), twiddles
+        self.chan = L.DeviceBuffer(64)
+        self.alphas = L.DeviceBuffer(16 * (columns[0].domain.logSize() + 2))
+        self._dch = None
+        # one eager run: fills the allocator's free lists with exactly the blocks the sequence needs and performs the
+        # one-time kernel set-up, so that the captured run issues nothing but launches
+        from .channel import Blake2sChannel
+        self._dch = DeviceChannel(Blake2sChannel(), buf=self.chan)
+        FriProver._commit_layers(config, self.columns, twiddles, _DeviceTranscript(self._dch, self.alphas))
+        L.sync()
+        L.call("tstwo_graph_begin_capture")
+        try:
+            self.first_layer, self.inner, self.last_eval = FriProver._commit_layers(
+                config, self.columns, twiddles, _DeviceTranscript(self._dch, self.alphas))
+        finally:
+            h = C.c_void_p()
+            L.call("tstwo_graph_end_capture", C.byref(h))
+        self._exec = h
+
+    def run(self, channel) -> FriProver:
+        self._dch.load(channel)                                   # host channel state -> device (64 bytes)
+        L.call("tstwo_graph_launch", self._exec)
+        self._dch.sync_to_host()
+        for layer in [self.first_layer] + self.inner:             # roots are re-read lazily from the freshly written layers
+            layer.merkle_tree._root = None
+        last = FriProver._commit_last_layer(channel, self.config, self.last_eval, self.twiddles)
+        return FriProver(self.config, self.first_layer, self.inner, last)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_exec", None):
+                L.call("tstwo_graph_destroy", self._exec)
+        except Exception:
+            pass
+
