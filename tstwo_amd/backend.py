@@ -134,11 +134,12 @@ class SecureColumnByCoords:
         for p in positions:
             if p < 0 or p >= n:
                 raise IndexError(f"Index {p} out of bounds for column of length {n}")
-        srcs = L.ptr_array([c.ptr for c in self.columns for _ in positions])
+        srcs = (L.vp * (4 * k))(*[c.ptr for c in self.columns for _ in range(k)])
         idx = (C.c_uint64 * (4 * k))(*(positions * 4))
         out = np.empty(4 * k, dtype=np.uint32)
         L.call("tstwo_gather_words", srcs, idx, 1, 4 * k, out.ctypes.data_as(L.u32p))
-        return [QM31.from_u32_unchecked(*(int(out[c * k + i]) for c in range(4))) for i in range(k)]
+        rows = out.reshape(4, k).T.tolist()
+        return [QM31.from_u32_unchecked(*r) for r in rows]
 
     def to_numpy(self): return [c.to_numpy() for c in self.columns]
     def to_vec(self): return [QM31.from_u32_unchecked(*map(int, t)) for t in zip(*self.to_numpy())]

@@ -8,6 +8,8 @@
 // The compression is VALU-bound (~1.2k lane-ops per 64-byte block, ~19 ops/byte) — DESIGN.md §Merkle
 // prices it against the integer-issue ceiling as well as the HBM roofline the bench reports.
 // Algorithmic bytes for a layer of n nodes: 4*C*n (+ 64*n children) read, 32*n written.
+#include <string.h>
+
 #include <vector>
 
 #include "common.h"
@@ -663,18 +665,31 @@ int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *
     if (q_src.size() > cap_q || h_src.size() > cap_h || w_src.size() > cap_w ||
         (q_src.size() && !queried_values) || (h_src.size() && !hash_witness) || (w_src.size() && !column_witness))
         return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: output buffer too small (required counts returned)");
-    int rc = tstwo_gather_words(h_src.data(), h_idx.data(), 8, h_src.size(), (u32 *)hash_witness);
+    // one upload of all request items, two launches (8-word digests, 1-word column values), one read-back
+    const size_t nh = h_src.size(), nv = q_src.size() + w_src.size();
+    if (nh + nv == 0) return TSTWO_OK;
+    Context &c = ctx();
+    std::vector<GatherItem> items(nh + nv);
+    for (size_t i = 0; i < nh; i++) items[i] = {(const u32 *)h_src[i], h_idx[i]};
+    for (size_t i = 0; i < q_src.size(); i++) items[nh + i] = {(const u32 *)q_src[i], q_idx[i]};
+    for (size_t i = 0; i < w_src.size(); i++) items[nh + q_src.size() + i] = {(const u32 *)w_src[i], w_idx[i]};
+    const size_t items_bytes = ((items.size() * sizeof(GatherItem) + 63) / 64) * 64;
+    const size_t out_words = 8 * nh + nv;
+    int rc = ensure_scratch(items_bytes + out_words * sizeof(u32));
     if (rc) return rc;
-    // queried values and column witness share one launch: gather into a temporary, then split
-    std::vector<const void *> v_src(q_src);
-    v_src.insert(v_src.end(), w_src.begin(), w_src.end());
-    std::vector<uint64_t> v_idx(q_idx);
-    v_idx.insert(v_idx.end(), w_idx.begin(), w_idx.end());
-    std::vector<u32> vals(v_src.size());
-    rc = tstwo_gather_words(v_src.data(), v_idx.data(), 1, v_src.size(), vals.data());
+    rc = small_h2d(c.scratch, items.data(), items.size() * sizeof(GatherItem));
     if (rc) return rc;
-    for (size_t i = 0; i < q_src.size(); i++) queried_values[i] = vals[i];
-    for (size_t i = 0; i < w_src.size(); i++) column_witness[i] = vals[q_src.size() + i];
+    const GatherItem *d_items = (const GatherItem *)c.scratch;
+    u32 *d_out = (u32 *)((unsigned char *)c.scratch + items_bytes);
+    if (nh) hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(8 * nh, 256)), dim3(256), 0, c.stream, d_items, 8u, 8 * nh, d_out);
+    if (nv) hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(nv, 256)), dim3(256), 0, c.stream, d_items + nh, 1u, nv, d_out + 8 * nh);
+    TSTWO_LAUNCH_CHECK();
+    std::vector<u32> host(out_words);
+    rc = small_d2h(host.data(), d_out, out_words * sizeof(u32));
+    if (rc) return rc;
+    if (nh) memcpy(hash_witness, host.data(), 32 * nh);
+    for (size_t i = 0; i < q_src.size(); i++) queried_values[i] = host[8 * nh + i];
+    for (size_t i = 0; i < w_src.size(); i++) column_witness[i] = host[8 * nh + q_src.size() + i];
     return TSTWO_OK;
 }
 

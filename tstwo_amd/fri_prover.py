@@ -186,7 +186,7 @@ class FriFirstLayerProver:
             pos, wit = compute_decommitment_positions_and_witness_evals(column.values, cq.positions, CIRCLE_TO_LINE_FOLD_STEP)
             positions_by_log[lg] = pos
             fri_witness += wit
-        _, dec = self.merkle_tree.decommit(positions_by_log, [cc for c in self.columns for cc in c.values.columns])
+        _, dec = self.merkle_tree.decommit(positions_by_log, [cc for c in self.columns for cc in c.values.columns], want_queried=False)
         return FriLayerProof(fri_witness, dec, self.merkle_tree.root())
 
 
@@ -198,7 +198,7 @@ class FriInnerLayerProver:
 
     def decommit(self, queries: Queries) -> FriLayerProof:
         pos, wit = compute_decommitment_positions_and_witness_evals(self.evaluation.values, queries.positions, FOLD_STEP)
-        _, dec = self.merkle_tree.decommit({self.evaluation.domain().logSize(): pos}, self.evaluation.values.columns)
+        _, dec = self.merkle_tree.decommit({self.evaluation.domain().logSize(): pos}, self.evaluation.values.columns, want_queried=False)
         return FriLayerProof(wit, dec, self.merkle_tree.root())
 
 

@@ -80,7 +80,7 @@ class MerkleProver:
         """Device address of the root (byte 0 of the layers buffer) for consumers that stay on the device."""
         return self._buf.ptr
 
-    def decommit(self, queriesPerLogSize: dict, columns) -> tuple:
+    def decommit(self, queriesPerLogSize: dict, columns, want_queried: bool = True) -> tuple:
         """MerkleProver.decommit (vcs/prover.ts:32-109): returns (queried_values, MerkleDecommitment).
         The walk over the layers and the two device gathers run inside the library (tstwo_merkle_decommit);
         `_decommit_walk` below is the same walk on the host mirror, kept for cross-checking."""
@@ -104,8 +104,9 @@ class MerkleProver:
                queried.ctypes.data_as(L.u32p), C.byref(n_q), hashes.ctypes.data_as(L.u8p), C.byref(n_h),
                colwit.ctypes.data_as(L.u32p), C.byref(n_w))
         hb = hashes.tobytes()
-        dec = MerkleDecommitment([hb[32 * i:32 * i + 32] for i in range(n_h.value)], [M31(int(v)) for v in colwit[:n_w.value]])
-        return [M31(int(v)) for v in queried[:n_q.value]], dec
+        dec = MerkleDecommitment([hb[32 * i:32 * i + 32] for i in range(n_h.value)], [M31(v) for v in colwit[:n_w.value].tolist()])
+        # (FRI layers already hold their queried evaluations: want_queried=False skips building the M31 list)
+        return ([M31(v) for v in queried[:n_q.value].tolist()] if want_queried else None), dec
 
     def _decommit_walk(self, queriesPerLogSize: dict, columns) -> tuple:
         """The reference's walk (vcs/prover.ts:32-109) planned on the host (decommit_requests) + two tstwo_gather_words calls;
