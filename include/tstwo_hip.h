@@ -225,6 +225,14 @@ int tstwo_quotients_accumulate(uint32_t half_initial, uint32_t log_size, const u
                                const uint32_t *col_idx, const uint32_t *abc, const uint32_t *batch_coeff,
                                const uint32_t *prx, const uint32_t *pry, const uint32_t *pix,
                                const uint32_t *piy, uint32_t *const out[4]);
+/* The same from the samples themselves: the quotient constants (quotientConstants, backend/cpu/quotients.ts:124-152,183-191;
+ * complexConjugateLineCoeffs, constraints.ts:117-128; Rust conjugation semantics) are computed by the library.
+ * points: 8 words per batch (QM31 x, QM31 y); values: 4 words per entry; batch b owns entries [batch_off[b], batch_off[b+1]).
+ * A sample point equal to its own conjugate -> TSTWO_ERR_BAD_ARG "Cannot evaluate a line with a single point". */
+int tstwo_quotients_accumulate_samples(uint32_t half_initial, uint32_t log_size, const uint32_t *const *cols, size_t n_cols,
+                                       size_t n_batches, const uint32_t *batch_off, const uint32_t *col_idx,
+                                       const uint32_t *points, const uint32_t *values, const uint32_t random_coeff[4],
+                                       uint32_t *const out[4]);
 
 #ifdef __cplusplus
 }

@@ -613,3 +613,32 @@ def test_many_columns_evaluate_extended():
     for c in (0, 63, 64, 79):
         ext = np.concatenate([polys[c], np.zeros((1 << n) - (1 << n_poly), dtype=np.uint32)])
         assert (host(out[c], 1 << n) == orc.cfft_evaluate(ext, n, half_odds(n - 1), otw, n - 1)).all()
+
+
+@pytest.mark.parametrize("log", [1, 3, 9, 14])
+def test_quotients_from_samples_vs_oracle(log, golden):
+    """tstwo_quotients_accumulate_samples (constants computed inside the library) == the oracle's per-row reference loop."""
+    px, py = golden["eval_at_point"][0]["point"]
+    n_cols = 6
+    cols = [rand_column(45000 + log * 8 + c, 1 << log) for c in range(n_cols)]
+    vals = [tuple(int(x) for x in rand_column(45500 + j, 4)) for j in range(7)]
+    py2 = OL.orc_qm31_mul(orc.q(py), orc.q(py)).tup()
+    batches = [(px, py, [(0, vals[0]), (3, vals[1]), (5, vals[2])]), (py, py2, [(1, vals[3])]), (px, py2, [(2, vals[4]), (0, vals[5]), (4, vals[6])])]
+    d = [dev(c) for c in cols]
+    out = [L.DeviceBuffer(max(4 << log, 16)) for _ in range(4)]
+    off, cidx, points, values = [0], [], [], []
+    for bx, by, cv in batches:
+        points += [*bx, *by]
+        for ci, v in cv:
+            cidx.append(ci)
+            values += list(v)
+        off.append(len(cidx))
+    L.call("tstwo_quotients_accumulate_samples", half_odds(log - 1), log, ptrs(d), n_cols, len(batches), L.u32x(off), L.u32x(cidx),
+           L.u32x(points), L.u32x(values), L.u32x((1, 2, 3, 4)), p4(out))
+    exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (1, 2, 3, 4), batches)
+    for k in range(4):
+        assert (host(out[k], 1 << log) == exp[k]).all()
+    # a sample point whose y is its own conjugate (base-field y) cannot define a line
+    with pytest.raises(L.TstwoError, match="Cannot evaluate a line with a single point"):
+        L.call("tstwo_quotients_accumulate_samples", half_odds(log - 1), log, ptrs(d), n_cols, 1, L.u32x([0, 1]), L.u32x([0]),
+               L.u32x([1, 2, 3, 4, 5, 6, 0, 0]), L.u32x([1, 1, 1, 1]), L.u32x((1, 2, 3, 4)), p4(out))

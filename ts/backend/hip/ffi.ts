@@ -65,6 +65,7 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_merkle_decommit: { args: [u64, u32, P, P, u64, P, P, P, u64, P, P, P, P, P, P], returns: i32 },
   tstwo_gather_words: { args: [P, P, u32, u64, P], returns: i32 },
   tstwo_grind_blake2s: { args: [P, u32, u64, P], returns: i32 },
+  tstwo_quotients_accumulate_samples: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P], returns: i32 },
   tstwo_quotients_accumulate: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P, P, P, P], returns: i32 },
 });
 

@@ -86,6 +86,7 @@ _SIGS = {
                               C.POINTER(C.c_size_t), C.c_size_t, u32p, C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_size_t),
                               u32p, C.POINTER(C.c_size_t)],
     "tstwo_gather_words": [C.POINTER(vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_size_t, u32p],
+    "tstwo_quotients_accumulate_samples": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p, u32p, u32p, P4],
     "tstwo_quotients_accumulate": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,
                                    u32p, u32p, u32p, u32p, u32p, P4],
 }

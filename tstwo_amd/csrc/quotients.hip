@@ -212,4 +212,47 @@ int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const 
     return TSTWO_OK;
 }
 
+
+// QuotientOps.accumulate_quotients from the SAMPLES (backend/cpu/quotients.ts:52-75 + quotientConstants :124-152,183-191 +
+// complexConjugateLineCoeffs, constraints.ts:117-128; Rust semantics: conj(a + bu) = a - bu, Pr = c0, Pi = c1): the per-entry
+// line coefficients (alpha^j a, alpha^j b, alpha^j c) and the per-batch alpha^{#cols} are computed here on the host side of
+// the library — a few QM31 multiplications per sampled column — and handed to tstwo_quotients_accumulate.
+// points: 8 words per batch (x then y, QM31 each); values: 4 words per entry, entries of batch b are
+// [batch_off[b], batch_off[b+1]).
+int tstwo_quotients_accumulate_samples(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
+                                       const u32 *batch_off, const u32 *col_idx, const u32 *points, const u32 *values,
+                                       const u32 random_coeff[4], u32 *const out[4]) {
+    TSTWO_REQUIRE_READY();
+    if (n_batches) TSTWO_REQUIRE_PTRS(batch_off, col_idx, points, values, random_coeff);
+    const size_t n_entries = n_batches ? batch_off[n_batches] : 0;
+    auto load = [](const u32 *p) { host::Q q; for (int k = 0; k < 4; k++) q.v[k] = p[k]; return q; };
+    auto conj = [](host::Q q) { q.v[2] = host::neg(q.v[2]); q.v[3] = host::neg(q.v[3]); return q; };   // (c0, -c1)
+    const host::Q rc = load(random_coeff);
+    std::vector<u32> abc(12 * n_entries + 4), bco(4 * n_batches + 4), prx(2 * n_batches + 2), pry(2 * n_batches + 2),
+        pix(2 * n_batches + 2), piy(2 * n_batches + 2);
+    for (size_t b = 0; b < n_batches; b++) {
+        const host::Q px = load(points + 8 * b), py = load(points + 8 * b + 4);
+        const host::Q cy = conj(py);
+        bool same = true;
+        for (int k = 0; k < 4; k++) same = same && cy.v[k] == py.v[k];
+        if (same) return set_error(TSTWO_ERR_BAD_ARG, "Cannot evaluate a line with a single point");   // constraints.ts:120
+        const host::Q c = host::qsub(cy, py);
+        host::Q alpha = {{1, 0, 0, 0}}, bc = {{1, 0, 0, 0}};
+        for (size_t j = batch_off[b]; j < batch_off[b + 1]; j++) {
+            alpha = host::qmul(alpha, rc);
+            bc = host::qmul(bc, rc);
+            const host::Q v = load(values + 4 * j);
+            const host::Q a = host::qsub(conj(v), v);
+            const host::Q bb = host::qsub(host::qmul(v, c), host::qmul(a, py));
+            const host::Q ea = host::qmul(alpha, a), eb = host::qmul(alpha, bb), ec = host::qmul(alpha, c);
+            for (int k = 0; k < 4; k++) { abc[12 * j + k] = ea.v[k]; abc[12 * j + 4 + k] = eb.v[k]; abc[12 * j + 8 + k] = ec.v[k]; }
+        }
+        for (int k = 0; k < 4; k++) bco[4 * b + k] = bc.v[k];
+        prx[2 * b] = px.v[0]; prx[2 * b + 1] = px.v[1]; pix[2 * b] = px.v[2]; pix[2 * b + 1] = px.v[3];
+        pry[2 * b] = py.v[0]; pry[2 * b + 1] = py.v[1]; piy[2 * b] = py.v[2]; piy[2 * b + 1] = py.v[3];
+    }
+    return tstwo_quotients_accumulate(half_initial, log_size, cols, n_cols, n_batches, batch_off, col_idx, abc.data(), bco.data(),
+                                      prx.data(), pry.data(), pix.data(), piy.data(), out);
+}
+
 }  // extern "C"

@@ -75,9 +75,31 @@ def accumulateQuotients(domain: CircleDomain, columns, random_coeff: QM31, sampl
     """accumulateQuotients (quotients.ts:52-75).  Default = Rust semantics (QM31 conjugation (c0,-c1); Pr/Pi = the
     c0/c1 parts of the sample point).  ts_compat=True reproduces the TS port's deviations (per-CM31 conjugation,
     qm31.ts:433-435; Pr/Pi taken from c0.real/c0.imag, quotients.ts:168-174) — see DESIGN.md "reference quirks"."""
-    _vals, args = marshal_quotient_args(domain, columns, random_coeff, sample_batches, ts_compat)
     out = SecureColumnByCoords.uninitialized(domain.size())
-    L.call("tstwo_quotients_accumulate", *args, out.ptrs())
+    if ts_compat:
+        _vals, args = marshal_quotient_args(domain, columns, random_coeff, sample_batches, ts_compat)
+        L.call("tstwo_quotients_accumulate", *args, out.ptrs())
+        return SecureEvaluation(domain, out)
+    # Rust semantics: the constants are computed inside the library from the samples (tstwo_quotients_accumulate_samples)
+    vals = [c.values if isinstance(c, HipCircleEvaluation) else c for c in columns]
+    for v in vals:
+        if v.len() != domain.size():
+            raise ValueError("column length does not match the domain size")
+    off, cidx, points, values = [0], [], [], []
+    for sb in sample_batches:
+        points += [*sb.point.x.tup(), *sb.point.y.tup()]
+        for ci, v in sb.columns_and_values:
+            cidx.append(ci)
+            values += v.tup()
+        off.append(len(cidx))
+    try:
+        L.call("tstwo_quotients_accumulate_samples", domain.halfCoset.initial_index.value, domain.log_size(),
+               L.ptr_array([v.ptr for v in vals]), len(vals), len(sample_batches), L.u32x(off), L.u32x(cidx), L.u32x(points),
+               L.u32x(values), L.u32x(as_q4(random_coeff)), out.ptrs())
+    except L.TstwoError as e:
+        if "single point" in str(e):
+            raise ValueError(str(e)) from None                   # complexConjugateLineCoeffs' own error (constraints.ts:120)
+        raise
     return SecureEvaluation(domain, out)
 
 
