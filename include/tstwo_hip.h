@@ -200,6 +200,22 @@ int tstwo_merkle_decommit(const uint8_t *layers, uint32_t max_log, const uint32_
                           const uint64_t *const *queries, const size_t *n_queries, size_t n_query_sets,
                           uint32_t *queried_values, size_t *n_queried, uint8_t *hash_witness, size_t *n_hashes,
                           uint32_t *column_witness, size_t *n_column_witness);
+/* The same for several trees in ONE round trip (all layers of a FRI proof; all trees of a commitment scheme).  Outputs are the
+ * per-request outputs concatenated in request order; counts[3r..3r+2] = (queried values, hashes, column-witness words) of
+ * request r; totals[3] is in/out (capacities in elements / required sizes), like the single-tree call. */
+typedef struct {
+    const uint8_t *layers;                 /* device: the tree's tstwo_merkle_commit buffer */
+    uint32_t max_log;
+    const uint32_t *const *cols;           /* host array of device column pointers */
+    const uint32_t *col_log_sizes;
+    size_t n_cols;
+    const uint32_t *query_logs;            /* query set k: n_queries[k] ascending positions queries[k][] of layer query_logs[k] */
+    const uint64_t *const *queries;
+    const size_t *n_queries;
+    size_t n_query_sets;
+} tstwo_decommit_request;
+int tstwo_merkle_decommit_many(const tstwo_decommit_request *reqs, size_t n_reqs, uint32_t *queried_values,
+                               uint8_t *hash_witness, uint32_t *column_witness, size_t *counts, size_t totals[3]);
 /* Gather for MerkleProver.decommit (vcs/prover.ts:32-109): item i = `words` consecutive uint32 words starting at
  * word index idx[i]*words of the device buffer srcs[i] (a column: words = 1; a layer of digests: words = 8).
  * Results land contiguously in host_out (n_items * words words).  srcs / idx are host arrays.  Synchronises. */

@@ -1137,3 +1137,23 @@ def test_fri_commit_plan_graph_replay_equals_eager():
         v = T.FriVerifier.commit(vch, cfg, proof, [T.CirclePolyDegreeBound(LOGD)])
         assert v.sample_query_positions(vch) == positions
         v.decommit(_query_evals([col], positions))
+
+
+def test_merkle_decommit_many_equals_individual_calls():
+    """tstwo_merkle_decommit_many (one round trip for several trees) == tstwo_merkle_decommit per tree."""
+    rng = np.random.default_rng(36000)
+    reqs = []
+    for t in range(5):
+        logs = sorted([int(rng.integers(1, 11)) for _ in range(int(rng.integers(1, 6)))], reverse=True)
+        cols = [T.HipColumn(rand_column(36000 + 10 * t + i, 1 << lg)) for i, lg in enumerate(logs)]
+        tree = T.MerkleProver.commit(cols)
+        queries = {lg: sorted(set(int(x) for x in rng.integers(0, 1 << lg, size=4))) for lg in set(logs)}
+        queries[12] = [5]                              # a size this tree does not have: ignored
+        reqs.append((tree, queries, cols))
+    many = T.MerkleProver.decommit_many(reqs)
+    for (tree, queries, cols), (qv, dec) in zip(reqs, many):
+        qv1, dec1 = tree.decommit(queries, cols)
+        assert [v.value for v in qv] == [v.value for v in qv1]
+        assert dec.hashWitness == dec1.hashWitness and [v.value for v in dec.columnWitness] == [v.value for v in dec1.columnWitness]
+        T.MerkleVerifier(T.Blake2sMerkleHasher, tree.root(), [c.len().bit_length() - 1 for c in cols]).verify(queries, qv, dec)
+    assert T.MerkleProver.decommit_many([]) == []

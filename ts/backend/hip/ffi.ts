@@ -63,6 +63,9 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_merkle_commit: { args: [P, P, u64, u64, P], returns: i32 },
   tstwo_merkle_layers_bytes: { args: [u32], returns: u64 },
   tstwo_merkle_decommit: { args: [u64, u32, P, P, u64, P, P, P, u64, P, P, P, P, P, P], returns: i32 },
+  // reqs: a packed array of tstwo_decommit_request structs (9 x 8 bytes each: layers, max_log (u32, padded), cols, col_log_sizes,
+  // n_cols, query_logs, queries, n_queries, n_query_sets) written into a BigUint64Array
+  tstwo_merkle_decommit_many: { args: [P, u64, P, P, P, P, P], returns: i32 },
   tstwo_gather_words: { args: [P, P, u32, u64, P], returns: i32 },
   tstwo_grind_blake2s: { args: [P, u32, u64, P], returns: i32 },
   tstwo_quotients_accumulate_samples: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P], returns: i32 },

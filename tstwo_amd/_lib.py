@@ -29,6 +29,13 @@ vp = C.c_void_p
 P4 = vp * 4
 P2 = vp * 2
 
+class DecommitRequest(C.Structure):
+    """tstwo_decommit_request (include/tstwo_hip.h)."""
+    _fields_ = [("layers", vp), ("max_log", C.c_uint32), ("cols", C.POINTER(vp)), ("col_log_sizes", u32p), ("n_cols", C.c_size_t),
+                ("query_logs", u32p), ("queries", C.POINTER(C.POINTER(C.c_uint64))), ("n_queries", C.POINTER(C.c_size_t)),
+                ("n_query_sets", C.c_size_t)]
+
+
 _SIGS = {
     "tstwo_init": [C.c_int],
     "tstwo_shutdown": [],
@@ -85,6 +92,7 @@ _SIGS = {
     "tstwo_merkle_decommit": [vp, C.c_uint32, C.POINTER(vp), u32p, C.c_size_t, u32p, C.POINTER(C.POINTER(C.c_uint64)),
                               C.POINTER(C.c_size_t), C.c_size_t, u32p, C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_size_t),
                               u32p, C.POINTER(C.c_size_t)],
+    "tstwo_merkle_decommit_many": [C.POINTER(DecommitRequest), C.c_size_t, u32p, u8p, u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "tstwo_gather_words": [C.POINTER(vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_size_t, u32p],
     "tstwo_quotients_accumulate_samples": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p, u32p, u32p, P4],
     "tstwo_quotients_accumulate": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,

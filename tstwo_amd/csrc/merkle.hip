@@ -612,30 +612,30 @@ int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, u32 words, 
 // MerkleProver.decommit (vcs/prover.ts:32-109) against device-resident layers and columns: the walk over the layers
 // (which nodes are visited, which child digests / column values the verifier cannot recompute) runs here on the host
 // side of the library; the selected words are then fetched with two gathers.
-int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *cols, const u32 *col_log_sizes, size_t n_cols,
-                          const u32 *query_logs, const uint64_t *const *queries, const size_t *n_queries, size_t n_query_sets,
-                          u32 *queried_values, size_t *n_queried, uint8_t *hash_witness, size_t *n_hashes,
-                          u32 *column_witness, size_t *n_column_witness) {
-    TSTWO_REQUIRE_READY();
-    if (!layers || !n_queried || !n_hashes || !n_column_witness || (n_cols && (!cols || !col_log_sizes)) ||
-        (n_query_sets && (!query_logs || !queries || !n_queries)))
+// The walk of one tree (vcs/prover.ts:32-109): appends the requests to the shared lists.
+struct DecommitLists {
+    std::vector<GatherItem> hashes, queried, witness;      // (device base, element index); digests are 8 words, values 1
+};
+static int plan_decommit(const uint8_t *layers, u32 max_log, const u32 *const *cols, const u32 *col_log_sizes, size_t n_cols,
+                         const u32 *query_logs, const uint64_t *const *queries, const size_t *n_queries, size_t n_query_sets,
+                         DecommitLists &out) {
+    if (!layers || (n_cols && (!cols || !col_log_sizes)) || (n_query_sets && (!query_logs || !queries || !n_queries)))
         return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: null argument");
     if (max_log > 31) return set_error(TSTWO_ERR_BAD_ARG, "merkle: log size out of range");
     TSTWO_REQUIRE_TABLE(cols, n_cols);
     for (size_t i = 0; i < n_cols; i++)
         if (col_log_sizes[i] > max_log) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: column larger than the tree");
-    std::vector<const void *> h_src, q_src, w_src;
-    std::vector<uint64_t> h_idx, q_idx, w_idx;
     std::vector<uint64_t> last, cur;
     for (int lg = (int)max_log; lg >= 0; lg--) {
         const uint64_t *direct = nullptr;
         size_t nd = 0;
         for (size_t k = 0; k < n_query_sets; k++)
             if (query_logs[k] == (u32)lg) { direct = queries[k]; nd = n_queries[k]; }
+        if (nd && !direct) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: null argument");
         for (size_t k = 0; k < nd; k++)
             if (direct[k] >> lg) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: query position outside its layer");
         const bool has_child = (u32)lg < max_log;
-        const uint8_t *child_layer = has_child ? layers + 32 * (((size_t)1 << (lg + 1)) - 1) : nullptr;
+        const u32 *child_layer = has_child ? (const u32 *)(layers + 32 * (((size_t)1 << (lg + 1)) - 1)) : nullptr;
         size_t pi = 0, di = 0;
         cur.clear();
         for (;;) {
@@ -647,32 +647,29 @@ int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *
             if (has_child)
                 for (uint64_t k = 2 * node; k <= 2 * node + 1; k++) {
                     if (pi < last.size() && last[pi] == k) pi++;
-                    else { h_src.push_back(child_layer); h_idx.push_back(k); }
+                    else out.hashes.push_back({child_layer, k});
                 }
             const bool queried = di < nd && direct[di] == node;
             if (queried) di++;
             for (size_t i = 0; i < n_cols; i++)          // columns of this layer, in the caller's order (stable sort by size)
-                if (col_log_sizes[i] == (u32)lg) {
-                    (queried ? q_src : w_src).push_back(cols[i]);
-                    (queried ? q_idx : w_idx).push_back(node);
-                }
+                if (col_log_sizes[i] == (u32)lg) (queried ? out.queried : out.witness).push_back({cols[i], node});
             cur.push_back(node);
         }
         last.swap(cur);
     }
-    const size_t cap_q = *n_queried, cap_h = *n_hashes, cap_w = *n_column_witness;
-    *n_queried = q_src.size(); *n_hashes = h_src.size(); *n_column_witness = w_src.size();
-    if (q_src.size() > cap_q || h_src.size() > cap_h || w_src.size() > cap_w ||
-        (q_src.size() && !queried_values) || (h_src.size() && !hash_witness) || (w_src.size() && !column_witness))
-        return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: output buffer too small (required counts returned)");
-    // one upload of all request items, two launches (8-word digests, 1-word column values), one read-back
-    const size_t nh = h_src.size(), nv = q_src.size() + w_src.size();
+    return TSTWO_OK;
+}
+
+// One upload of all request items, two launches (8-word digests, 1-word column values), one read-back.
+static int run_decommit(const DecommitLists &l, u32 *queried_values, uint8_t *hash_witness, u32 *column_witness) {
+    const size_t nh = l.hashes.size(), nq = l.queried.size(), nw = l.witness.size(), nv = nq + nw;
     if (nh + nv == 0) return TSTWO_OK;
     Context &c = ctx();
-    std::vector<GatherItem> items(nh + nv);
-    for (size_t i = 0; i < nh; i++) items[i] = {(const u32 *)h_src[i], h_idx[i]};
-    for (size_t i = 0; i < q_src.size(); i++) items[nh + i] = {(const u32 *)q_src[i], q_idx[i]};
-    for (size_t i = 0; i < w_src.size(); i++) items[nh + q_src.size() + i] = {(const u32 *)w_src[i], w_idx[i]};
+    std::vector<GatherItem> items;
+    items.reserve(nh + nv);
+    items.insert(items.end(), l.hashes.begin(), l.hashes.end());
+    items.insert(items.end(), l.queried.begin(), l.queried.end());
+    items.insert(items.end(), l.witness.begin(), l.witness.end());
     const size_t items_bytes = ((items.size() * sizeof(GatherItem) + 63) / 64) * 64;
     const size_t out_words = 8 * nh + nv;
     int rc = ensure_scratch(items_bytes + out_words * sizeof(u32));
@@ -688,9 +685,52 @@ int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *
     rc = small_d2h(host.data(), d_out, out_words * sizeof(u32));
     if (rc) return rc;
     if (nh) memcpy(hash_witness, host.data(), 32 * nh);
-    for (size_t i = 0; i < q_src.size(); i++) queried_values[i] = host[8 * nh + i];
-    for (size_t i = 0; i < w_src.size(); i++) column_witness[i] = host[8 * nh + q_src.size() + i];
+    if (nq) memcpy(queried_values, host.data() + 8 * nh, 4 * nq);
+    if (nw) memcpy(column_witness, host.data() + 8 * nh + nq, 4 * nw);
     return TSTWO_OK;
+}
+
+int tstwo_merkle_decommit(const uint8_t *layers, u32 max_log, const u32 *const *cols, const u32 *col_log_sizes, size_t n_cols,
+                          const u32 *query_logs, const uint64_t *const *queries, const size_t *n_queries, size_t n_query_sets,
+                          u32 *queried_values, size_t *n_queried, uint8_t *hash_witness, size_t *n_hashes,
+                          u32 *column_witness, size_t *n_column_witness) {
+    TSTWO_REQUIRE_READY();
+    if (!n_queried || !n_hashes || !n_column_witness) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: null argument");
+    DecommitLists l;
+    int rc = plan_decommit(layers, max_log, cols, col_log_sizes, n_cols, query_logs, queries, n_queries, n_query_sets, l);
+    if (rc) return rc;
+    const size_t cap_q = *n_queried, cap_h = *n_hashes, cap_w = *n_column_witness;
+    *n_queried = l.queried.size(); *n_hashes = l.hashes.size(); *n_column_witness = l.witness.size();
+    if (l.queried.size() > cap_q || l.hashes.size() > cap_h || l.witness.size() > cap_w ||
+        (l.queried.size() && !queried_values) || (l.hashes.size() && !hash_witness) || (l.witness.size() && !column_witness))
+        return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: output buffer too small (required counts returned)");
+    return run_decommit(l, queried_values, hash_witness, column_witness);
+}
+
+// Several trees in one round trip (every layer of a FRI proof, every tree of a commitment scheme): request r is described by
+// reqs[r]; the outputs are the concatenation of the per-tree outputs in request order, counts[3r..3r+2] = (queried values,
+// hashes, column witness words) of request r.  totals[3] is in/out like the single-tree call (capacities / required sizes).
+int tstwo_merkle_decommit_many(const tstwo_decommit_request *reqs, size_t n_reqs, u32 *queried_values, uint8_t *hash_witness,
+                               u32 *column_witness, size_t *counts, size_t totals[3]) {
+    TSTWO_REQUIRE_READY();
+    if ((n_reqs && (!reqs || !counts)) || !totals) return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: null argument");
+    DecommitLists l;
+    for (size_t r = 0; r < n_reqs; r++) {
+        const size_t q0 = l.queried.size(), h0 = l.hashes.size(), w0 = l.witness.size();
+        const tstwo_decommit_request &q = reqs[r];
+        int rc = plan_decommit(q.layers, q.max_log, q.cols, q.col_log_sizes, q.n_cols, q.query_logs, q.queries, q.n_queries,
+                               q.n_query_sets, l);
+        if (rc) return rc;
+        counts[3 * r] = l.queried.size() - q0;
+        counts[3 * r + 1] = l.hashes.size() - h0;
+        counts[3 * r + 2] = l.witness.size() - w0;
+    }
+    const size_t cap_q = totals[0], cap_h = totals[1], cap_w = totals[2];
+    totals[0] = l.queried.size(); totals[1] = l.hashes.size(); totals[2] = l.witness.size();
+    if (l.queried.size() > cap_q || l.hashes.size() > cap_h || l.witness.size() > cap_w ||
+        (l.queried.size() && !queried_values) || (l.hashes.size() && !hash_witness) || (l.witness.size() && !column_witness))
+        return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: output buffer too small (required counts returned)");
+    return run_decommit(l, queried_values, hash_witness, column_witness);
 }
 
 // Device-resident Blake2sChannel (state: 10 words = digest[8], n_challenges, n_sent).  root: 32 bytes in device memory

@@ -140,6 +140,25 @@ class FriProof:
     last_layer_poly: LinePoly
 
 
+def _decommitment_positions(query_positions, fold_step: int) -> tuple:
+    """The index part of fri.ts:346-384: (decommitment positions, positions whose evaluation the verifier cannot compute)."""
+    decommitment_positions, witness_positions = [], []
+    qs = list(query_positions)
+    i = 0
+    while i < len(qs):
+        coset = qs[i] >> fold_step
+        start = coset << fold_step
+        subset = set()
+        while i < len(qs) and (qs[i] >> fold_step) == coset:
+            subset.add(qs[i])
+            i += 1
+        for position in range(start, start + (1 << fold_step)):
+            decommitment_positions.append(position)
+            if position not in subset:
+                witness_positions.append(position)
+    return decommitment_positions, witness_positions
+
+
 def compute_decommitment_positions_and_witness_evals(column: SecureColumnByCoords, query_positions, fold_step: int):
     """fri.ts:346-384.  Same walk; the witness values are fetched from the device column with ONE gather."""
     decommitment_positions, witness_positions = [], []
@@ -324,14 +343,44 @@ class FriProver:
         return self.decommit_on_queries(queries), by_log
 
     def decommit_on_queries(self, queries: Queries) -> FriProof:
-        """fri.ts:768-785."""
-        first = self.first_layer.decommit(queries)
-        inner = []
+        """fri.ts:768-785.  The positions of every layer are planned first; then ONE gather fetches all witness evaluations
+        and ONE tstwo_merkle_decommit_many call decommits all trees (instead of three round trips per layer)."""
+        plans = []                      # (tree, positions_by_log, merkle columns, [(SecureColumnByCoords, witness positions)])
+        max_log = queries.log_domain_size
+        assert max_log == self.first_layer.max_column_log_size()
+        by_log, wit = {}, []
+        for column in self.first_layer.columns:
+            lg = column.domain.logSize()
+            pos, wpos = _decommitment_positions(queries.fold(max_log - lg).positions, CIRCLE_TO_LINE_FOLD_STEP)
+            by_log[lg] = pos
+            wit.append((column.values, wpos))
+        plans.append((self.first_layer.merkle_tree, by_log, [cc for c in self.first_layer.columns for cc in c.values.columns], wit))
         layer_queries = queries.fold(CIRCLE_TO_LINE_FOLD_STEP)
         for layer in self.inner_layers:
-            inner.append(layer.decommit(layer_queries))
+            pos, wpos = _decommitment_positions(layer_queries.positions, FOLD_STEP)
+            plans.append((layer.merkle_tree, {layer.evaluation.domain().logSize(): pos}, layer.evaluation.values.columns,
+                          [(layer.evaluation.values, wpos)]))
             layer_queries = layer_queries.fold(FOLD_STEP)
-        return FriProof(first, inner, self.last_layer_poly)
+        # all witness evaluations with one device gather
+        flat = [(vals, p) for _, _, _, w in plans for vals, wp in w for p in wp]
+        k = len(flat)
+        witness = []
+        if k:
+            import ctypes as C
+
+            import numpy as np
+            srcs = (L.vp * (4 * k))(*[vals.columns[c].ptr for c in range(4) for vals, _ in flat])
+            idx = (C.c_uint64 * (4 * k))(*([p for _, p in flat] * 4))
+            out = np.empty(4 * k, dtype=np.uint32)
+            L.call("tstwo_gather_words", srcs, idx, 1, 4 * k, out.ctypes.data_as(L.u32p))
+            witness = [QM31.from_u32_unchecked(*r) for r in out.reshape(4, k).T.tolist()]
+        decs = MerkleProver.decommit_many([(t, q, cols) for t, q, cols, _ in plans], want_queried=False)
+        proofs, w0 = [], 0
+        for (tree, _, _, w), (_, dec) in zip(plans, decs):
+            n_w = sum(len(wp) for _, wp in w)
+            proofs.append(FriLayerProof(witness[w0:w0 + n_w], dec, tree.root()))
+            w0 += n_w
+        return FriProof(proofs[0], proofs[1:], self.last_layer_poly)
 
     decommitOnQueries = decommit_on_queries
 

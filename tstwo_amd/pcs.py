@@ -183,6 +183,6 @@ class CommitmentSchemeProver:
         channel.mix_u64(proof_of_work)
         # FRI decommitment phase, then the trace trees on the same queries
         fri_proof, query_positions = fri_prover.decommit(channel)
-        results = [t.decommit(query_positions) for t in self.trees]
+        results = MerkleProver.decommit_many([(t.commitment, query_positions, [ev.values for ev in t.evaluations]) for t in self.trees])
         return CommitmentSchemeProof(self.config, self.roots(), sampled_values, [d for _, d in results],
                                      [v for v, _ in results], proof_of_work, fri_proof)

@@ -108,6 +108,47 @@ class MerkleProver:
         # (FRI layers already hold their queried evaluations: want_queried=False skips building the M31 list)
         return ([M31(v) for v in queried[:n_q.value].tolist()] if want_queried else None), dec
 
+    @staticmethod
+    def decommit_many(requests, want_queried: bool = True) -> list:
+        """decommit() of several trees in ONE round trip (tstwo_merkle_decommit_many): `requests` = [(tree, queriesPerLogSize,
+        columns)]; returns [(queried_values or None, MerkleDecommitment)] in request order."""
+        requests = list(requests)
+        if not requests:
+            return []
+        keep, reqs = [], (L.DecommitRequest * len(requests))()
+        cap_v = cap_h = 1
+        for r, (tree, qpl, columns) in enumerate(requests):
+            cols = list(columns)
+            max_log = len(tree.layers) - 1
+            sets = [(lg, list(q)) for lg, q in qpl.items() if q and 0 <= lg <= max_log]
+            total_q = sum(len(q) for _, q in sets)
+            cap_v += total_q * max(1, len(cols))
+            cap_h += 2 * total_q * (max_log + 1)
+            qarrs = [(C.c_uint64 * max(len(q), 1))(*q) for _, q in sets]
+            qptrs = (C.POINTER(C.c_uint64) * max(len(sets), 1))(*[C.cast(a, C.POINTER(C.c_uint64)) for a in qarrs])
+            nq = (C.c_size_t * max(len(sets), 1))(*[len(q) for _, q in sets])
+            colp = L.ptr_array([c.ptr for c in cols])
+            logs = L.u32x([c.len().bit_length() - 1 for c in cols])
+            qlogs = L.u32x([lg for lg, _ in sets])
+            keep += [qarrs, qptrs, nq, colp, logs, qlogs]
+            reqs[r] = L.DecommitRequest(tree._buf.ptr, max_log, colp, logs, len(cols), qlogs, qptrs, nq, len(sets))
+        queried = np.empty(cap_v, dtype=np.uint32)
+        colwit = np.empty(cap_v, dtype=np.uint32)
+        hashes = np.empty(32 * cap_h, dtype=np.uint8)
+        counts = (C.c_size_t * (3 * len(requests)))()
+        totals = (C.c_size_t * 3)(cap_v, cap_h, cap_v)
+        L.call("tstwo_merkle_decommit_many", reqs, len(requests), queried.ctypes.data_as(L.u32p), hashes.ctypes.data_as(L.u8p),
+               colwit.ctypes.data_as(L.u32p), counts, totals)
+        hb = hashes.tobytes()
+        out, q0, h0, w0 = [], 0, 0, 0
+        ql, wl = queried.tolist() if want_queried else None, colwit[:totals[2]].tolist()
+        for r in range(len(requests)):
+            nq_, nh_, nw_ = counts[3 * r], counts[3 * r + 1], counts[3 * r + 2]
+            dec = MerkleDecommitment([hb[32 * (h0 + i):32 * (h0 + i) + 32] for i in range(nh_)], [M31(v) for v in wl[w0:w0 + nw_]])
+            out.append(([M31(v) for v in ql[q0:q0 + nq_]] if want_queried else None, dec))
+            q0, h0, w0 = q0 + nq_, h0 + nh_, w0 + nw_
+        return out
+
     def _decommit_walk(self, queriesPerLogSize: dict, columns) -> tuple:
         """The reference's walk (vcs/prover.ts:32-109) planned on the host (decommit_requests) + two tstwo_gather_words calls;
         kept to cross-check the in-library tstwo_merkle_decommit."""
