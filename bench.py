@@ -69,14 +69,12 @@ def cpu_oracle():
 
 
 def cpu_baseline(sample_cols: int, threads: int = 0):
-    """CPU oracle (oracle/, 'port') timed beside the GPU step, two legs on a bounded sample:
+    """CPU oracle (oracle/, kind "port": -O3 scalar C) timed beside the GPU step on a bounded sample:
       * one thread: `sample_cols` of the 32 columns — CFFT evaluate + Merkle commit over them;
-      * all cores (reported as cpu_baseline.value): the full 32-column step, column-parallel CFFT (one column per task)
-        and a row-sharded Merkle tree (each thread hashes a contiguous leaf range to a subtree root; the top levels are
-        combined with hashlib) on `threads` threads (default: min(cores, 32), a power of two).  ctypes releases the GIL.
-    Both are the same scalar C code; nothing here is on the GPU path."""
-    import hashlib
-    from concurrent.futures import ThreadPoolExecutor
+      * all host cores (reported as cpu_baseline.value): the FULL 32-column step on C threads (oracle/tstwo_oracle_mt.c:
+        one column per task for the CFFT, the leaf range cut into contiguous shards for the Merkle tree, whose root equals
+        the single-tree root) — `threads` = every core the process may run on unless given.
+    Returns the record and the oracle's root of the step's input, which main() compares with the GPU's."""
     orc = cpu_oracle()
     n = LOG_SIZE
     half = orc.lib().orc_half_odds_initial(n - 1)
@@ -92,33 +90,29 @@ def cpu_baseline(sample_cols: int, threads: int = 0):
         "sample": f"{sample_cols} of {COLS_PER_GPU} columns x 2^{n}: CFFT evaluate ({t1 - t0:.2f} s) + Merkle commit over them ({t2 - t1:.2f} s)",
         "cfft_butterflies_per_s": sample_cols * n * (1 << (n - 1)) / (t1 - t0),
     }
-    cores = os.cpu_count() or 1
+    del evs
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     if threads <= 0:
-        threads = 1
-        while threads * 2 <= min(cores, 32):
-            threads *= 2
-    if threads < 2:
-        return dict(single, kind="port", sample=single["sample"] + f", 1 thread; host has {cores} cores")
+        threads = cores
     all_cols = cols + [splitmix_column(100 + c, 1 << n) for c in range(sample_cols, COLS_PER_GPU)]
-    with ThreadPoolExecutor(max_workers=threads) as pool:
-        t3 = time.perf_counter()
-        evs = list(pool.map(lambda c: orc.cfft_evaluate(c, n, half, tw, n - 1), all_cols))
-        t4 = time.perf_counter()
-        rows = (1 << n) // threads
-        lg = n - (threads.bit_length() - 1)
-        sub = list(pool.map(lambda r: orc.merkle_commit([e[r * rows:(r + 1) * rows] for e in evs], [lg] * len(evs))[1], range(threads)))
-        while len(sub) > 1:
-            sub = [hashlib.blake2s(sub[2 * i] + sub[2 * i + 1]).digest() for i in range(len(sub) // 2)]
-        t5 = time.perf_counter()
+    t3 = time.perf_counter()
+    orc.mt_cfft_evaluate(all_cols, n, half, tw, n - 1, threads)       # in place
+    t4 = time.perf_counter()
+    root = orc.mt_merkle_root(all_cols, n, threads)
+    t5 = time.perf_counter()
     return {
         "value": COLS_PER_GPU * (1 << n) / (t5 - t3),
         "unit": "elems/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"the full step ({COLS_PER_GPU} columns x 2^{n}) on {threads} threads of the host's {cores} cores: column-parallel CFFT "
-                  f"({t4 - t3:.2f} s) + row-sharded Merkle commit ({t5 - t4:.2f} s); {threads * (t5 - t3):.0f} core-seconds",
+        "sample": f"the full step ({COLS_PER_GPU} columns x 2^{n}) on {threads} C threads = every core this process may use "
+                  f"(os.cpu_count() = {os.cpu_count()}): column-parallel CFFT ({t4 - t3:.2f} s) + leaf-sharded Merkle commit "
+                  f"({t5 - t4:.2f} s); oracle built -O3",
         "cfft_butterflies_per_s": COLS_PER_GPU * n * (1 << (n - 1)) / (t4 - t3),
-        "root": sub[0].hex()[:16],
+        "root": root.hex(),
         "single_thread": single,
     }
 
@@ -132,6 +126,8 @@ def main():
     ap.add_argument("--log-size", type=int, default=LOG_SIZE)
     ap.add_argument("--cpu-cols", type=int, default=4, help="columns in the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-4 (the `configs` list of the JSON line)")
+    ap.add_argument("--pmc-json", default=None, help="tools/pmc_summary.py output of a --pmc run of THIS command: fills roofline.traffic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -237,7 +233,11 @@ def main():
         L.sync()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Correctness of the measured workload: the first (untimed) step runs on the fresh synthetic input; its root is
+    # compared below with the CPU oracle's root of the same 32 x 2^22 columns (cpu_baseline.root) -> "root_match".
+    step(None)
+    gpu_root_first = bytes(layers.download(np.uint8, 32).tobytes())
+    for _ in range(max(args.warmup - 1, 0)):
         step(None)
     barrier()
     t0 = time.perf_counter()
@@ -269,13 +269,13 @@ def main():
         launch_ms = cfft_ms / passes
         achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9
         merkle_bytes = (4.0 * n_cols + 64.0) * N                    # 4*C*N read + 64*N written
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_cfft_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM traffic is a PMC measurement of a separate rocprofv3 --pmc run of this same command; it enters the line only
+        # when that run's summary is handed in (tools/refresh_profiles.sh does), never from a stale committed file.
+        traffic, traffic_source = None, None
+        if args.pmc_json and os.path.exists(args.pmc_json):
+            pj = json.load(open(args.pmc_json))
+            traffic = pj.get("hbm_bytes_per_launch")
+            traffic_source = {"file": os.path.relpath(args.pmc_json, ROOT), "kernels": pj.get("kernels"), "lib_sha16": pj.get("lib_sha16")}
         out = {
             "metric": "M31 CFFT elems/sec at log_size=22 (per step: CFFT evaluate + Blake2s Merkle commit + root all-gather)",
             "value": total_elems / elapsed,
@@ -300,7 +300,7 @@ def main():
             "merkle_GBps": merkle_bytes / (merkle_ms * 1e-3) / 1e9,
             "merkle_frac_of_hbm_peak": merkle_bytes / (merkle_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9> + fast::k_cfft_b<false,13> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": passes, "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          # the kernel is VALU-bound, so the lane-op rate is reported next to the HBM fraction.
@@ -311,11 +311,22 @@ def main():
                                   "frac": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK}},
             "device": L.device_name(),
         }
-        if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE and world == 1:   # rank 0 at N = 1 only
+        root_ok = None
+        if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE and n_cols == COLS_PER_GPU and world == 1:   # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_cols)
+            root_ok = out["cpu_baseline"]["root"] == gpu_root_first.hex()
         else:
             out["cpu_baseline"] = None
+        out["gpu_root"] = gpu_root_first.hex()
+        out["root_match"] = root_ok            # GPU root of the first step == CPU oracle root of the same input (None: oracle leg not run)
+        if world == 1 and not args.no_configs:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from bench_configs import run_configs
+            del dev_cols[:]
+            out["configs"] = run_configs(reps=10, no_cpu=args.no_cpu)      # BASELINE configs 1-4, same JSON line
         print(json.dumps(out), flush=True)
+        if root_ok is False:
+            raise SystemExit("bench.py: the GPU Merkle root of the 32 x 2^22 step differs from the CPU oracle's: the measured numbers are void")
 
     if use_dist:
         dist.barrier()

@@ -18,7 +18,11 @@
  *    HOST arrays of device pointers, borrowed for the duration of the call.
  *  - Work is enqueued on one HIP stream per process (tstwo_set_stream to borrow the caller's).
  *    Calls that hand results to host memory synchronise; the others are asynchronous and ordered
- *    on that stream; tstwo_sync() drains it.  Thread-compatible: the caller serialises calls.
+ *    on that stream; tstwo_sync() drains it.
+ *  - Threading: the library is thread-compatible — one thread at a time inside it, the caller
+ *    serialises calls — with one exception: tstwo_malloc / tstwo_free / tstwo_trim lock the
+ *    allocator, so a block may be released from any thread (a finaliser / GC thread under ctypes or
+ *    bun:ffi, which drop the interpreter lock during a call) while another thread is in a call.
  *  - No CPU fallback exists: every entry point fails with an error if no GPU is present.
  */
 #ifndef TSTWO_HIP_H
@@ -52,7 +56,19 @@ int tstwo_sync(void);
 int tstwo_malloc(void **dev, size_t bytes);
 int tstwo_free(void *dev);                   /* returns the block to the library's caching allocator (no sync) */
 int tstwo_trim(void);                        /* synchronises and gives every cached block back to HIP */
-int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);     /* synchronous */
+/* Where tstwo_malloc gets its blocks.  POOL (default): size-class free lists over hipMalloc, reuse ordered on the
+ * library's stream.  DIRECT: hipMalloc / hipFree per call (free synchronises).  ASYNC: HIP's stream-ordered pool
+ * (hipMallocAsync / hipFreeAsync on the library's stream).  OR in POISON to have every block handed out filled with
+ * 0xA5 bytes first (debugging aid: reads of memory the library never wrote stop looking right by accident).
+ * Environment, read at the first tstwo_malloc: TSTWO_ALLOC=pool|direct|async, TSTWO_POISON=1. */
+#define TSTWO_ALLOC_POOL 0
+#define TSTWO_ALLOC_DIRECT 1
+#define TSTWO_ALLOC_ASYNC 2
+#define TSTWO_ALLOC_POISON 0x10
+int tstwo_set_alloc_mode(int mode);
+/* The host buffer may be reused as soon as tstwo_upload returns; the copy itself is ordered on the stream (small
+ * uploads travel through a page-locked ring without a host synchronisation, large ones synchronise). */
+int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
 int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes);        /* async d2d */
 int tstwo_zero(void *dev, size_t bytes);                                  /* async; Column.zeros, backend/index.ts:56 */
@@ -82,6 +98,15 @@ int tstwo_m31_neg(const uint32_t *a, uint32_t *out, size_t n);
 int tstwo_m31_batch_inverse(const uint32_t *in, uint32_t *out, size_t n);
 int tstwo_cm31_batch_inverse(const uint32_t *const in[2], uint32_t *const out[2], size_t n);
 int tstwo_qm31_batch_inverse(const uint32_t *const in[4], uint32_t *const out[4], size_t n);
+/* Deferred error reporting for a phase of many small calls: the *_async variants only enqueue the kernel; a zero input
+ * sets a sticky flag in device memory instead of failing the call (the affected outputs are unspecified).
+ * tstwo_check_zero_flag() synchronises ONCE, clears the flag and fails with TSTWO_ERR_ZERO_INVERSE ("0 has no
+ * inverse", fields/m31.ts:139) if any call since the last check met a zero.  The synchronous calls above are
+ * unchanged (= async + check). */
+int tstwo_m31_batch_inverse_async(const uint32_t *in, uint32_t *out, size_t n);
+int tstwo_cm31_batch_inverse_async(const uint32_t *const in[2], uint32_t *const out[2], size_t n);
+int tstwo_qm31_batch_inverse_async(const uint32_t *const in[4], uint32_t *const out[4], size_t n);
+int tstwo_check_zero_flag(void);
 /* QM31.mul / QM31.add per element on SoA columns (fields/qm31.ts:168-233) */
 int tstwo_qm31_mul(const uint32_t *const a[4], const uint32_t *const b[4], uint32_t *const out[4], size_t n);
 /* AccumulationOps.accumulate: col[i] += other[i] (backend/cpu/accumulation.ts:38-49) */
@@ -249,6 +274,16 @@ int tstwo_quotients_accumulate_samples(uint32_t half_initial, uint32_t log_size,
                                        size_t n_batches, const uint32_t *batch_off, const uint32_t *col_idx,
                                        const uint32_t *points, const uint32_t *values, const uint32_t random_coeff[4],
                                        uint32_t *const out[4]);
+/* The same two calls without the read-back: a vanishing denominator sets the sticky zero flag (tstwo_check_zero_flag). */
+int tstwo_quotients_accumulate_async(uint32_t half_initial, uint32_t log_size, const uint32_t *const *cols,
+                                     size_t n_cols, size_t n_batches, const uint32_t *batch_off,
+                                     const uint32_t *col_idx, const uint32_t *abc, const uint32_t *batch_coeff,
+                                     const uint32_t *prx, const uint32_t *pry, const uint32_t *pix,
+                                     const uint32_t *piy, uint32_t *const out[4]);
+int tstwo_quotients_accumulate_samples_async(uint32_t half_initial, uint32_t log_size, const uint32_t *const *cols,
+                                             size_t n_cols, size_t n_batches, const uint32_t *batch_off,
+                                             const uint32_t *col_idx, const uint32_t *points, const uint32_t *values,
+                                             const uint32_t random_coeff[4], uint32_t *const out[4]);
 
 #ifdef __cplusplus
 }

@@ -34,8 +34,8 @@ class OracleError(Exception):
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (Makefile next to this file)."""
-    src = os.path.join(_HERE, "tstwo_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("tstwo_oracle.c", "tstwo_oracle_mt.c", "tstwo_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return _SO
 
@@ -119,6 +119,8 @@ def lib():
                                                           C.POINTER(CM31), C.POINTER(CM31), C.POINTER(CM31), P4]),
             "orc_accumulate": (None, [P4, P4, sz]),
             "orc_generate_secure_powers": (None, [QM31, sz, C.POINTER(QM31)]),
+            "orc_mt_cfft_evaluate": (C.c_int, [C.POINTER(u32p), sz, u32, u32, u32p, u32, C.c_uint]),
+            "orc_mt_merkle_root": (C.c_int, [C.POINTER(u32p), sz, u32, C.c_uint, u8p]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -346,3 +348,21 @@ def generate_secure_powers(felt, n):
     out = (QM31 * max(n, 1))()
     lib().orc_generate_secure_powers(q(felt), n, out)
     return [out[i].tup() for i in range(n)]
+
+
+# ------------------------------------------------------------------ pthread drivers (tstwo_oracle_mt.c)
+def mt_cfft_evaluate(cols, log_size, half_initial, tw, tw_log, threads):
+    """In-place evaluate of every column (uint32 arrays, modified), one column per task on `threads` C threads."""
+    cols = [c if (isinstance(c, np.ndarray) and c.dtype == np.uint32 and c.flags.c_contiguous) else _u32(c) for c in cols]
+    arr = (u32p * max(len(cols), 1))(*[_p(c) for c in cols])
+    tw = _u32(tw)
+    _chk(lib().orc_mt_cfft_evaluate(arr, len(cols), log_size, half_initial, _p(tw), tw_log, threads))
+    return cols
+
+
+def mt_merkle_root(cols, log_size, threads) -> bytes:
+    """Root of MerkleProver.commit over equal-length columns, leaf range sharded over `threads` C threads."""
+    cols, arr = _colptrs(cols)
+    root = np.zeros(32, dtype=np.uint8)
+    _chk(lib().orc_mt_merkle_root(arr, len(cols), log_size, threads, _p8(root)))
+    return root.tobytes()

@@ -305,7 +305,7 @@ static const u32 *line_tw(const u32 *buf, size_t L, u32 n, u32 j, size_t *len) {
 }
 /* backend/cpu/circle.ts:270-278 */
 static u32 *circle_tw(const u32 *first, size_t len) {
-    u32 *res = (u32 *)malloc((2 * len ? 2 * len : 1) * sizeof(u32));
+    u32 *res = (u32 *)malloc((len ? 2 * len : 1) * sizeof(u32));
     for (size_t i = 0; i + 1 < len; i += 2) {
         u32 x = first[i], y = first[i + 1];
         res[2 * i] = y; res[2 * i + 1] = orc_m31_neg(y); res[2 * i + 2] = orc_m31_neg(x); res[2 * i + 3] = x;

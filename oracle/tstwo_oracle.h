@@ -7,8 +7,8 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
  * library; the product (tstwo_amd/, libtstwo_hip.so) never does.
  *
- * Parity status: PINNED for the field arithmetic (test-vectors/*.json, 817
- * Rust-generated vectors), Blake2s (absolute KATs in test/vcs/*.test.ts) and
+ * Parity status: PINNED for the field arithmetic (test-vectors/{m31,cm31,qm31,securecolumn}-test-vectors.json, 817
+ * Rust-generated vectors), Blake2s (absolute KATs in test/vcs/{blake2_hash,blake2s_ref}.test.ts) and
  * the twiddle-slicing rule (test/poly/domainLineTwiddles.test.ts).  CFFT, FRI
  * folds, quotients and Merkle layers have no golden vectors in the reference;
  * they are pinned by (i) the reference's own mathematical property tests,
@@ -160,6 +160,12 @@ int orc_accumulate_quotients_consts(uint32_t half_initial, uint32_t log_size, co
 /* ---- accumulation (backend/cpu/accumulation.ts:38-63) ---- */
 void orc_accumulate(uint32_t *const col[4], const uint32_t *const other[4], size_t n);
 void orc_generate_secure_powers(orc_qm31 felt, size_t n, orc_qm31 *out);
+
+/* ---- pthread drivers (tstwo_oracle_mt.c): the same functions above run by several threads, for full-size parity tests and
+ * the all-cores CPU baseline.  cols are transformed in place, one column per task; the Merkle root is the single-tree root. */
+int orc_mt_cfft_evaluate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,
+                         const uint32_t *tw, uint32_t tw_log, unsigned threads);
+int orc_mt_merkle_root(const uint32_t *const *cols, size_t n_cols, uint32_t log_size, unsigned threads, uint8_t root[32]);
 
 #ifdef __cplusplus
 }

@@ -57,3 +57,11 @@ def rand_column(seed, n, nonzero=False):
     rng = np.random.default_rng(seed)
     lo = 1 if nonzero else 0
     return rng.integers(lo, P, size=n, dtype=np.uint32)
+
+
+def golden_interp_values(e):
+    """Input of a cfft_interpolate golden entry: inline list (log <= 5) or base64 of the LE32 words."""
+    import base64
+    if "values" in e:
+        return np.array(e["values"], dtype=np.uint32)
+    return np.frombuffer(base64.b64decode(e["values_b64"]), dtype="<u4").astype(np.uint32)

@@ -172,9 +172,28 @@ def poly_eval_qm31(coeffs, px, py):
     return total
 
 
+def basis_at(n, p):
+    """[b_k(p) for k < 2^n], b_k = y^{k0} x^{k1} pi(x)^{k2} ...: the same monomials as poly_eval_m31, expanded once per point."""
+    factors = [p[1]]
+    x = p[0]
+    for _ in range(1, n):
+        factors.append(x)
+        x = (2 * x * x - 1) % P
+    b = [1]
+    for f in factors:
+        b = b + [v * f % P for v in b]
+    return b
+
+
 def evaluate(coeffs, n):
     half = half_odds(n - 1)
-    return [poly_eval_m31(coeffs, domain_at(half, bitrev(i, n))) for i in range(1 << n)]
+    if n <= 8:
+        return [poly_eval_m31(coeffs, domain_at(half, bitrev(i, n))) for i in range(1 << n)]
+    out = []
+    for i in range(1 << n):          # log 9, 10: sum_k c_k b_k(p) with the basis expanded once per point
+        b = basis_at(n, domain_at(half, bitrev(i, n)))
+        out.append(sum(c * v for c, v in zip(coeffs, b)) % P)
+    return out
 
 
 def fold_line(vals, k, coset, alpha):
@@ -267,9 +286,11 @@ def main():
         g["twiddles"].append(e)
     g["slicing_kat"] = {"buffer": list(range(8)), "log_line_domain": 3, "expect": [[0, 1, 2, 3], [4, 5], [6]]}
 
-    # CFFT by definition, log 1..8
+    # CFFT by definition, log 1..10: evaluate(coeffs) and, as its own known-answer pair with other seeds,
+    # interpolate: the values of a seeded polynomial on the domain (by definition) are the input, its coefficients the
+    # expected output (interpolate is the inverse map, backend/cpu/circle.ts:136-207).
     g["cfft"] = []
-    for n in range(1, 9):
+    for n in range(1, 11):
         coeffs = column(300 + n, 1 << n)
         ev = evaluate(coeffs, n)
         e = {"log": n, "half_initial": half_odds(n - 1)[0], "seed": 300 + n,
@@ -277,6 +298,17 @@ def main():
         if n <= 5:
             e["coeffs"], e["eval"] = coeffs, ev
         g["cfft"].append(e)
+    g["cfft_interpolate"] = []
+    for n in range(1, 11):
+        coeffs = column(350 + n, 1 << n)
+        vals = evaluate(coeffs, n)
+        e = {"log": n, "half_initial": half_odds(n - 1)[0], "coeffs_seed": 350 + n,
+             "values_digest": digest_u32([vals]), "coeffs_digest": digest_u32([coeffs])}
+        if n <= 5:
+            e["values"], e["coeffs"] = vals, coeffs
+        elif n <= 10:
+            e["values_b64"] = __import__("base64").b64encode(le32(vals)).decode()   # the input must travel: it is not seed-derived
+        g["cfft_interpolate"].append(e)
     # eval_at_point at the secure-field generator
     g["eval_at_point"] = []
     for n in range(0, 7):

@@ -31,16 +31,67 @@ def test_capi_exports_every_declared_symbol():
     assert lib.tstwo_merkle_layers_bytes(3) == 32 * 15
 
 
-def test_ts_binding_names_every_symbol():
-    """ts/backend/hip/ffi.ts (the bun:ffi stub of INTEGRATION.md) binds every symbol of the header, with as many arguments
-    as the ctypes binding has."""
+def _header_prototypes():
+    """{symbol: (return kind, [arg kinds])} parsed from include/tstwo_hip.h.  Kinds: 'ptr', 'u32', 'i32', 'u64'."""
+    src = open(os.path.join(ROOT, "include", "tstwo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(?:^|;|\})\s*((?:const\s+)?[A-Za-z_0-9]+\s*\**)\s*(tstwo_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?=;)", src, flags=re.S | re.M):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+
+        def kind(t):
+            t = " ".join(t.split())
+            if "*" in t or "[" in t:
+                return "ptr"
+            base = re.sub(r"\bconst\b", "", t).split()[0]
+            return {"uint32_t": "u32", "int": "i32", "size_t": "u64", "uint64_t": "u64"}[base]
+        kinds = [] if args in ("", "void") else [kind(a) for a in args.split(",")]
+        protos[name] = (kind(ret + " x") if "*" not in ret else "ptr", kinds)
+    return protos
+
+
+def test_ts_and_ctypes_bindings_match_the_header_prototypes():
+    """Three descriptions of the C ABI must agree argument by argument: the header's prototypes, the ctypes binding every
+    -m gpu test calls through (tstwo_amd/_lib.py), and ts/backend/hip/ffi.ts (the bun:ffi stub of INTEGRATION.md, which
+    cannot run in this image).  Scalars must have the header's width and signedness; a pointer is `u64` in ffi.ts exactly
+    where ctypes passes a raw device address (c_void_p) and `P` exactly where ctypes passes host memory."""
+    import ctypes as C
     ts = open(os.path.join(ROOT, "ts", "backend", "hip", "ffi.ts")).read()
+    protos = _header_prototypes()
+    assert set(protos) == set(L.EXPORTS), set(protos) ^ set(L.EXPORTS)
+
+    def ctypes_kind(t):
+        if t is C.c_void_p:
+            return "dev"
+        if t in (C.c_uint32,):
+            return "u32"
+        if t in (C.c_int,):
+            return "i32"
+        if t in (C.c_size_t, C.c_uint64):
+            return "u64"
+        return "host"           # POINTER(...), arrays of pointers, c_char_p: host memory
     for sym in L.EXPORTS:
-        m = re.search(rf"\b{sym}: \{{ args: \[([^\]]*)\]", ts)
+        m = re.search(rf"\b{sym}: \{{ args: \[([^\]]*)\], returns: (\w+)", ts)
         assert m, f"{sym} missing from ffi.ts"
-        n_ts = len([a for a in m.group(1).split(",") if a.strip()])
+        ts_args = [a.strip() for a in m.group(1).split(",") if a.strip()]
+        ret_kind, h_args = protos[sym]
+        assert len(ts_args) == len(h_args), (sym, ts_args, h_args)
+        assert m.group(2) == {"i32": "i32", "u64": "u64", "ptr": "cstring"}[ret_kind], (sym, m.group(2), ret_kind)
+        for i, (t, h) in enumerate(zip(ts_args, h_args)):
+            ok = (h == "ptr" and t in ("P", "u64")) or (h != "ptr" and t == h)
+            assert ok, f"{sym} argument {i}: ffi.ts says {t}, the header says {h}"
         if sym in L._SIGS:
-            assert n_ts == len(L._SIGS[sym]), (sym, n_ts, len(L._SIGS[sym]))
+            c_args = [ctypes_kind(t) for t in L._SIGS[sym]]
+            for i in L.HOST_VOID_ARGS.get(sym, ()):
+                assert c_args[i] == "dev"
+                c_args[i] = "host"
+            assert len(c_args) == len(h_args), (sym, c_args, h_args)
+            for i, (c, h, t) in enumerate(zip(c_args, h_args, ts_args)):
+                assert (c in ("dev", "host")) == (h == "ptr"), f"{sym} argument {i}: ctypes {c} vs header {h}"
+                if c in ("u32", "i32", "u64"):
+                    assert c == h, f"{sym} argument {i}: ctypes {c} vs header {h}"
+                want = {"dev": "u64", "host": "P"}.get(c, c)
+                assert t == want, f"{sym} argument {i}: ffi.ts {t}, ctypes binding implies {want}"
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -189,6 +189,25 @@ def test_cfft_golden(golden):
         assert hashlib.blake2s(host(d[0], 1 << n).tobytes()).hexdigest() == e["eval_digest"], n
 
 
+def test_cfft_interpolate_golden(golden):
+    """interpolate known answers log 1..10 (inputs travel in the fixture; expected = seeded coefficients)."""
+    from conftest import golden_interp_values
+    for e in golden["cfft_interpolate"]:
+        n = e["log"]
+        tw_log = max(n - 1, 1)
+        _, itw = build_twiddles(tw_log)
+        vals = golden_interp_values(e)
+        d = [dev(vals)]
+        L.call("tstwo_cfft_interpolate", ptrs(d), 1, n, e["half_initial"], vp(itw), tw_log)
+        got = host(d[0], 1 << n)
+        assert hashlib.blake2s(got.tobytes()).hexdigest() == e["coeffs_digest"], n
+        assert (got == column(e["coeffs_seed"], 1 << n)).all()
+        # out-of-place variant: same answer, source untouched
+        s, o = [dev(vals)], [dev_empty(1 << n)]
+        L.call("tstwo_cfft_interpolate_to", ptrs(s), ptrs(o), 1, n, e["half_initial"], vp(itw), tw_log)
+        assert (host(o[0], 1 << n) == got).all() and (host(s[0], 1 << n) == vals).all()
+
+
 def test_cfft_bigger_tree_and_errors():
     n = 10
     tw, itw = build_twiddles(14)

@@ -1,0 +1,84 @@
+"""-m gpu: BASELINE config 5's per-GPU shard AT FULL SIZE — 32 trace columns x 2^22, PolyOps.evaluate + MerkleProver.commit —
+bit-exact against the CPU oracle (every evaluation word, and the root), under every allocator mode of the library.
+
+This is the size class at which both intermittent faults of round 1 appeared (a missing LDS barrier in the inverse
+strided pass; "different Merkle roots run to run" with HIP's stream-ordered allocator), so it runs once in the normal
+GPU suite: pool (default), pool with poisoned blocks, direct hipMalloc, HIP's stream-ordered pool with and without
+poison.  Between the two commits of a mode every buffer is released and allocated again, so recycled blocks are in
+play, and the second commit uses the columns in reverse order (another root; the oracle only re-hashes).
+The oracle side is the threaded driver of oracle/tstwo_oracle_mt.c (same scalar C functions, one column per task).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from tstwo_amd import _lib as L  # noqa: E402
+from bench import splitmix_column  # noqa: E402
+
+N_LOG, N_COLS = 22, 32
+THREADS = max(1, min(16, os.cpu_count() or 1))
+
+
+@pytest.fixture(scope="module")
+def oracle_side():
+    n = N_LOG
+    half = orc.lib().orc_half_odds_initial(n - 1)
+    tw, _ = orc.precompute_twiddles(half, n - 1, inverse=False)
+    coeffs = [splitmix_column(100 + c, 1 << n) for c in range(N_COLS)]
+    evals = orc.mt_cfft_evaluate([c.copy() for c in coeffs], n, half, tw, n - 1, THREADS)
+    root_fwd = orc.mt_merkle_root(evals, n, THREADS)
+    root_rev = orc.mt_merkle_root(evals[::-1], n, THREADS)
+    assert root_fwd != root_rev
+    return half, coeffs, evals, root_fwd, root_rev
+
+
+def gpu_commit(half, coeffs, check_evals=None):
+    """Fresh buffers -> evaluate -> commit; returns the root (and compares every evaluation word when asked)."""
+    n, N = N_LOG, 1 << N_LOG
+    bufs = []
+    for c in coeffs:
+        b = L.DeviceBuffer(4 * N)
+        b.upload(c)
+        bufs.append(b)
+    tw = L.DeviceBuffer(4 * (N // 2))
+    L.call("tstwo_twiddles_build", half, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
+    ptrs = L.ptr_array([b.ptr for b in bufs])
+    L.call("tstwo_cfft_evaluate", ptrs, len(bufs), n, half, C.c_void_p(tw.ptr), n - 1)
+    layers = L.DeviceBuffer(32 * ((2 << n) - 1))
+    root = (C.c_uint8 * 32)()
+    L.call("tstwo_merkle_commit", ptrs, L.u32x([n] * len(bufs)), len(bufs), C.c_void_p(layers.ptr), root)
+    if check_evals is not None:
+        for i, (b, e) in enumerate(zip(bufs, check_evals)):
+            got = b.download(np.uint32, N)
+            assert (got == e).all(), f"evaluation column {i}: {int((got != e).sum())} words differ, first at {int(np.argmax(got != e))}"
+    # the root in the layers buffer is the one handed to the host
+    assert bytes(layers.download(np.uint8, 32)) == bytes(root)
+    for b in bufs:
+        b.free()
+    tw.free()
+    layers.free()
+    return bytes(root)
+
+
+MODES = [("pool", L.ALLOC_POOL), ("pool+poison", L.ALLOC_POOL | L.ALLOC_POISON), ("direct", L.ALLOC_DIRECT),
+         ("async", L.ALLOC_ASYNC), ("async+poison", L.ALLOC_ASYNC | L.ALLOC_POISON)]
+
+
+@pytest.mark.parametrize("name,mode", MODES, ids=[m[0] for m in MODES])
+def test_config5_shard_full_size_every_allocator(oracle_side, name, mode):
+    half, coeffs, evals, root_fwd, root_rev = oracle_side
+    L.init(0)
+    L.call("tstwo_set_alloc_mode", mode)
+    try:
+        assert gpu_commit(half, coeffs, check_evals=evals) == root_fwd, f"{name}: root of the 32 x 2^22 shard differs from the oracle's"
+        # everything was released: the second commit runs on recycled blocks, other column order
+        assert gpu_commit(half, coeffs[::-1]) == root_rev, f"{name}: root differs on recycled blocks"
+        assert gpu_commit(half, coeffs) == root_fwd, f"{name}: root differs on the third pass"
+    finally:
+        L.call("tstwo_set_alloc_mode", L.ALLOC_POOL)

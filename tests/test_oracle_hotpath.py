@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import P, column, rand_column
+from conftest import P, column, golden_interp_values, rand_column
 from oracle import oracle as orc
 
 L = orc.lib()
@@ -55,6 +55,23 @@ def test_cfft_golden(golden):
             assert ev.tolist() == e["eval"]
         back = orc.cfft_interpolate(ev, n, e["half_initial"], itw, tw_log)
         assert back.tolist() == coeffs.tolist()
+
+
+def test_cfft_interpolate_golden(golden):
+    """interpolate known answers log 1..10 (values of a seeded polynomial, stated by definition -> its coefficients)."""
+    assert [e["log"] for e in golden["cfft_interpolate"]] == list(range(1, 11))
+    assert [e["log"] for e in golden["cfft"]] == list(range(1, 11))
+    for e in golden["cfft_interpolate"]:
+        n = e["log"]
+        vals = golden_interp_values(e)
+        assert digest([vals]) == e["values_digest"]
+        tw_log = max(n - 1, 1)
+        _, itw = orc.precompute_twiddles(half_odds(tw_log), tw_log)
+        co = orc.cfft_interpolate(vals, n, e["half_initial"], itw, tw_log)
+        assert digest([co]) == e["coeffs_digest"], f"log {n}"
+        assert co.tolist() == column(e["coeffs_seed"], 1 << n).tolist()
+        if "coeffs" in e:
+            assert co.tolist() == e["coeffs"]
 
 
 @pytest.mark.parametrize("n", [3, 6, 10])

@@ -17,6 +17,7 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_set_stream: { args: [u64], returns: i32 },
   tstwo_sync: { args: [], returns: i32 },
   tstwo_trim: { args: [], returns: i32 },
+  tstwo_set_alloc_mode: { args: [i32], returns: i32 },
   tstwo_graph_begin_capture: { args: [], returns: i32 },
   tstwo_graph_end_capture: { args: [P], returns: i32 },
   tstwo_graph_launch: { args: [u64], returns: i32 },
@@ -38,6 +39,10 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_m31_batch_inverse: { args: [u64, u64, u64], returns: i32 },
   tstwo_cm31_batch_inverse: { args: [P, P, u64], returns: i32 },
   tstwo_qm31_batch_inverse: { args: [P, P, u64], returns: i32 },
+  tstwo_m31_batch_inverse_async: { args: [u64, u64, u64], returns: i32 },
+  tstwo_cm31_batch_inverse_async: { args: [P, P, u64], returns: i32 },
+  tstwo_qm31_batch_inverse_async: { args: [P, P, u64], returns: i32 },
+  tstwo_check_zero_flag: { args: [], returns: i32 },
   tstwo_qm31_mul: { args: [P, P, P, u64], returns: i32 },
   tstwo_secure_accumulate: { args: [P, P, u64], returns: i32 },
   tstwo_bit_reverse: { args: [P, u64, u64], returns: i32 },
@@ -70,6 +75,8 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_grind_blake2s: { args: [P, u32, u64, P], returns: i32 },
   tstwo_quotients_accumulate_samples: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P], returns: i32 },
   tstwo_quotients_accumulate: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P, P, P, P], returns: i32 },
+  tstwo_quotients_accumulate_samples_async: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P], returns: i32 },
+  tstwo_quotients_accumulate_async: { args: [u32, u32, P, u64, u64, P, P, P, P, P, P, P, P, P], returns: i32 },
 });
 
 export const hip = lib.symbols;

@@ -46,6 +46,7 @@ _SIGS = {
     "tstwo_malloc": [C.POINTER(vp), C.c_size_t],
     "tstwo_free": [vp],
     "tstwo_trim": [],
+    "tstwo_set_alloc_mode": [C.c_int],
     "tstwo_upload": [vp, vp, C.c_size_t],
     "tstwo_download": [vp, vp, C.c_size_t],
     "tstwo_copy": [vp, vp, C.c_size_t],
@@ -65,6 +66,10 @@ _SIGS = {
     "tstwo_m31_batch_inverse": [vp, vp, C.c_size_t],
     "tstwo_cm31_batch_inverse": [P2, P2, C.c_size_t],
     "tstwo_qm31_batch_inverse": [P4, P4, C.c_size_t],
+    "tstwo_m31_batch_inverse_async": [vp, vp, C.c_size_t],
+    "tstwo_cm31_batch_inverse_async": [P2, P2, C.c_size_t],
+    "tstwo_qm31_batch_inverse_async": [P4, P4, C.c_size_t],
+    "tstwo_check_zero_flag": [],
     "tstwo_qm31_mul": [P4, P4, P4, C.c_size_t],
     "tstwo_secure_accumulate": [P4, P4, C.c_size_t],
     "tstwo_bit_reverse": [C.POINTER(vp), C.c_size_t, C.c_size_t],
@@ -97,7 +102,13 @@ _SIGS = {
     "tstwo_quotients_accumulate_samples": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p, u32p, u32p, P4],
     "tstwo_quotients_accumulate": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,
                                    u32p, u32p, u32p, u32p, u32p, P4],
+    "tstwo_quotients_accumulate_samples_async": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p, u32p, u32p, P4],
+    "tstwo_quotients_accumulate_async": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,
+                                         u32p, u32p, u32p, u32p, u32p, P4],
 }
+ALLOC_POOL, ALLOC_DIRECT, ALLOC_ASYNC, ALLOC_POISON = 0, 1, 2, 0x10
+# c_void_p arguments above are DEVICE addresses, except these (host memory of any element type)
+HOST_VOID_ARGS = {"tstwo_upload": {1}, "tstwo_download": {0}}
 # every symbol include/tstwo_hip.h declares (tests check the library exports all of them)
 EXPORTS = sorted(list(_SIGS) + ["tstwo_last_error", "tstwo_version", "tstwo_merkle_layers_bytes"])
 

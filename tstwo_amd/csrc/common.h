@@ -23,9 +23,15 @@ struct Context {
     int n_cus = 256;
     u32 **coltab = nullptr;           // device: 2 pointer tables of coltab_cap entries each (fill_col_table)
     size_t coltab_cap = 0;
-    void *pinned = nullptr;           // page-locked host staging for small read-backs / uploads (kPinnedBytes)
+    void *pinned = nullptr;           // page-locked host staging for small read-backs (kPinnedBytes)
+    void *up_ring = nullptr;          // page-locked ring of kUpSlots upload slots (small_h2d: asynchronous uploads)
+    hipEvent_t up_done[16] = {};      // recorded behind the copy that last used the slot
+    bool up_busy[16] = {};
+    int up_next = 0;
 };
 constexpr size_t kPinnedBytes = 64 * 1024;
+constexpr int kUpSlots = 16;
+constexpr size_t kUpSlotBytes = 16 * 1024;
 
 Context &ctx();
 int set_error(int code, const char *msg);
@@ -35,8 +41,10 @@ int require_ready();
 int ensure_scratch(size_t bytes);
 // reads the device error flag (synchronises the stream) and clears it
 int read_and_clear_flag(u32 *value);
-// Small device->host / host->device transfers through the page-locked staging buffer: a pageable hipMemcpy of a few
-// bytes costs ~25 us on this stack, a pinned one ~10 us.  Both synchronise the stream (d2h after, h2d before returning).
+// Small device->host / host->device transfers through page-locked staging: a pageable hipMemcpy of a few bytes costs
+// ~25 us on this stack, a pinned one ~10 us.  small_d2h synchronises the stream (the data is in host memory on return);
+// small_h2d copies the source into a ring slot and returns with the transfer enqueued (stream-ordered, no host sync) for
+// sizes up to kUpSlotBytes, and synchronises for larger ones.
 int small_d2h(void *host_dst, const void *dev_src, size_t bytes);
 int small_h2d(void *dev_dst, const void *host_src, size_t bytes);
 

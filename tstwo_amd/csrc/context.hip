@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -65,15 +66,21 @@ int small_d2h(void *host_dst, const void *dev_src, size_t bytes) {
 int small_h2d(void *dev_dst, const void *host_src, size_t bytes) {
     Context &c = g_ctx;
     if (bytes == 0) return TSTWO_OK;
-    if (!c.pinned || bytes > kPinnedBytes) {
+    if (!c.up_ring || bytes > kUpSlotBytes) {
         TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.stream));
         TSTWO_HIP(hipStreamSynchronize(c.stream));
         return TSTWO_OK;
     }
-    // the staging buffer is reused by the next call, so the copy must have left it before we return
-    memcpy(c.pinned, host_src, bytes);
-    TSTWO_HIP(hipMemcpyAsync(dev_dst, c.pinned, bytes, hipMemcpyHostToDevice, c.stream));
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    // Ring of page-locked slots: the copy is enqueued and the call returns; a slot is rewritten only after the event
+    // recorded behind its previous copy has completed (kUpSlots uploads later — in practice long done, no wait).
+    const int k = c.up_next;
+    c.up_next = (k + 1) % kUpSlots;
+    if (c.up_busy[k]) TSTWO_HIP(hipEventSynchronize(c.up_done[k]));
+    unsigned char *slot = (unsigned char *)c.up_ring + (size_t)k * kUpSlotBytes;
+    memcpy(slot, host_src, bytes);
+    TSTWO_HIP(hipMemcpyAsync(dev_dst, slot, bytes, hipMemcpyHostToDevice, c.stream));
+    TSTWO_HIP(hipEventRecord(c.up_done[k], c.stream));
+    c.up_busy[k] = true;
     return TSTWO_OK;
 }
 static std::vector<const u32 *> g_coltab_last[2];       // host copy of what each device table slot holds
@@ -137,11 +144,17 @@ static u32 h_sub(u32 a, u32 b) { return a >= b ? a - b : a + M31_P - b; }
 using namespace tstwo;
 
 namespace {
+// Device allocator state.  tstwo_malloc / tstwo_free / tstwo_trim take `mu`, so a block may be released from any thread
+// (a garbage collector's finaliser thread, say) while another thread is inside the library; every other entry point is
+// thread-compatible only (include/tstwo_hip.h "Threading").
 struct Pool {
-    std::map<size_t, std::vector<void *>> free_lists;     // size class -> cached blocks
-    std::unordered_map<void *, size_t> live;               // block -> size class
+    std::mutex mu;
+    std::map<size_t, std::vector<void *>> free_lists;     // size class -> cached blocks (mode POOL)
+    struct Live { size_t bytes; int mode; };
+    std::unordered_map<void *, Live> live;                 // every block handed out by tstwo_malloc -> how to release it
     size_t cached_bytes = 0;
-    bool enabled = true, probed = false;
+    int mode = TSTWO_ALLOC_POOL;
+    bool poison = false, probed = false;
 };
 Pool g_pool;
 size_t size_class(size_t bytes) {
@@ -150,6 +163,24 @@ size_t size_class(size_t bytes) {
     while (p < bytes) p <<= 1;                            // 2^k ...
     if (bytes <= (p >> 1) + (p >> 2)) return (p >> 1) + (p >> 2);   // ... or 1.5 * 2^(k-1): at most 33 % slack
     return p;
+}
+void probe_env() {          // TSTWO_ALLOC=pool|direct|async, TSTWO_NO_POOL=1 (= direct), TSTWO_POISON=1
+    if (g_pool.probed) return;
+    g_pool.probed = true;
+    const char *m = getenv("TSTWO_ALLOC");
+    if (m && !strcmp(m, "direct")) g_pool.mode = TSTWO_ALLOC_DIRECT;
+    else if (m && !strcmp(m, "async")) g_pool.mode = TSTWO_ALLOC_ASYNC;
+    else if (getenv("TSTWO_NO_POOL")) g_pool.mode = TSTWO_ALLOC_DIRECT;
+    const char *p = getenv("TSTWO_POISON");
+    g_pool.poison = p && *p && strcmp(p, "0") != 0;
+}
+int trim_locked() {
+    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    for (auto &kv : g_pool.free_lists)
+        for (void *p : kv.second) (void)hipFree(p);
+    g_pool.free_lists.clear();
+    g_pool.cached_bytes = 0;
+    return TSTWO_OK;
 }
 }  // namespace
 
@@ -200,6 +231,9 @@ int tstwo_init(int device) {
     TSTWO_HIP(hipMalloc((void **)&c.flag, 64));
     TSTWO_HIP(hipMemset(c.flag, 0, 64));
     if (hipHostMalloc(&c.pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; (void)hipGetLastError(); }
+    if (hipHostMalloc(&c.up_ring, kUpSlots * kUpSlotBytes, hipHostMallocDefault) != hipSuccess) { c.up_ring = nullptr; (void)hipGetLastError(); }
+    if (c.up_ring)
+        for (int k = 0; k < kUpSlots; k++) TSTWO_HIP(hipEventCreateWithFlags(&c.up_done[k], hipEventDisableTiming));
     c.ready = true;
     return TSTWO_OK;
 }
@@ -208,12 +242,19 @@ int tstwo_shutdown(void) {
     Context &c = g_ctx;
     if (!c.ready) return TSTWO_OK;
     (void)hipStreamSynchronize(c.stream);
-    (void)tstwo_trim();
-    for (auto &kv : g_pool.live) (void)hipFree(kv.first);
-    g_pool.live.clear();
+    {
+        std::lock_guard<std::mutex> lock(g_pool.mu);
+        (void)trim_locked();
+        for (auto &kv : g_pool.live) (void)hipFree(kv.first);
+        g_pool.live.clear();
+    }
     if (c.gen_pow2) (void)hipFree(c.gen_pow2);
     if (c.flag) (void)hipFree(c.flag);
     if (c.pinned) (void)hipHostFree(c.pinned);
+    if (c.up_ring) {
+        for (int k = 0; k < kUpSlots; k++) (void)hipEventDestroy(c.up_done[k]);
+        (void)hipHostFree(c.up_ring);
+    }
     if (c.coltab) (void)hipFree(c.coltab);
     coltab_cache_reset();
     if (c.scratch) (void)hipFree(c.scratch);
@@ -287,11 +328,21 @@ int tstwo_sync(void) {
 
 int tstwo_trim(void) {
     if (!g_ctx.ready) return TSTWO_OK;
-    TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
-    for (auto &kv : g_pool.free_lists)
-        for (void *p : kv.second) (void)hipFree(p);
-    g_pool.free_lists.clear();
-    g_pool.cached_bytes = 0;
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    return trim_locked();
+}
+
+int tstwo_set_alloc_mode(int mode) {
+    TSTWO_REQUIRE_READY();
+    const int base = mode & 0xF;
+    if (base != TSTWO_ALLOC_POOL && base != TSTWO_ALLOC_DIRECT && base != TSTWO_ALLOC_ASYNC)
+        return set_error(TSTWO_ERR_BAD_ARG, "tstwo_set_alloc_mode: unknown mode");
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    g_pool.probed = true;
+    int rc = trim_locked();            // cached blocks go back to HIP; live blocks remember the mode they came from
+    if (rc) return rc;
+    g_pool.mode = base;
+    g_pool.poison = (mode & TSTWO_ALLOC_POISON) != 0;
     return TSTWO_OK;
 }
 
@@ -299,38 +350,57 @@ int tstwo_malloc(void **dev, size_t bytes) {
     TSTWO_REQUIRE_READY();
     if (!dev) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_malloc: null out pointer");
     *dev = nullptr;
-    if (!g_pool.probed) { g_pool.probed = true; g_pool.enabled = getenv("TSTWO_NO_POOL") == nullptr; }
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    probe_env();
     if (bytes == 0) bytes = 16;
-    const size_t cls = g_pool.enabled ? size_class(bytes) : bytes;
-    if (g_pool.enabled) {
+    const int mode = g_pool.mode;
+    const size_t cls = mode == TSTWO_ALLOC_POOL ? size_class(bytes) : bytes;
+    void *p = nullptr;
+    if (mode == TSTWO_ALLOC_POOL) {
         auto it = g_pool.free_lists.find(cls);
         if (it != g_pool.free_lists.end() && !it->second.empty()) {
-            *dev = it->second.back();
+            p = it->second.back();
             it->second.pop_back();
             g_pool.cached_bytes -= cls;
-            g_pool.live[*dev] = cls;
-            return TSTWO_OK;
         }
     }
-    hipError_t e = hipMalloc(dev, cls);
-    if (e != hipSuccess && g_pool.cached_bytes) {           // out of memory with blocks cached: give them back and retry
-        (void)hipGetLastError();
-        int rc = tstwo_trim();
-        if (rc) return rc;
-        e = hipMalloc(dev, cls);
+    if (!p) {
+        hipError_t e = mode == TSTWO_ALLOC_ASYNC ? hipMallocAsync(&p, cls, g_ctx.stream) : hipMalloc(&p, cls);
+        if (e != hipSuccess && g_pool.cached_bytes) {           // out of memory with blocks cached: give them back and retry
+            (void)hipGetLastError();
+            int rc = trim_locked();
+            if (rc) return rc;
+            e = mode == TSTWO_ALLOC_ASYNC ? hipMallocAsync(&p, cls, g_ctx.stream) : hipMalloc(&p, cls);
+        }
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     }
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
-    if (g_pool.enabled) g_pool.live[*dev] = cls;
+    g_pool.live[p] = {cls, mode};
+    // Debugging aid: a block handed out full of 0xA5 turns any read of memory the library never wrote into a
+    // deterministic mismatch (a recycled block otherwise holds whatever the previous owner left, often the right data).
+    if (g_pool.poison) TSTWO_HIP(hipMemsetAsync(p, 0xA5, cls, g_ctx.stream));
+    *dev = p;
     return TSTWO_OK;
 }
 int tstwo_free(void *dev) {
     if (!dev) return TSTWO_OK;
     TSTWO_REQUIRE_READY();
+    std::lock_guard<std::mutex> lock(g_pool.mu);
     auto it = g_pool.live.find(dev);
-    if (it != g_pool.live.end()) {
-        g_pool.free_lists[it->second].push_back(dev);
-        g_pool.cached_bytes += it->second;
-        g_pool.live.erase(it);
+    if (it == g_pool.live.end()) {           // not ours (or already released): the safe thing is a synchronous free
+        TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+        TSTWO_HIP(hipFree(dev));
+        return TSTWO_OK;
+    }
+    const Pool::Live l = it->second;
+    g_pool.live.erase(it);
+    if (l.mode == TSTWO_ALLOC_POOL && g_pool.mode == TSTWO_ALLOC_POOL) {
+        // Reuse is stream-ordered: the next owner's first access is enqueued behind every operation that used the block.
+        g_pool.free_lists[l.bytes].push_back(dev);
+        g_pool.cached_bytes += l.bytes;
+        return TSTWO_OK;
+    }
+    if (l.mode == TSTWO_ALLOC_ASYNC) {
+        TSTWO_HIP(hipFreeAsync(dev, g_ctx.stream));
         return TSTWO_OK;
     }
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));

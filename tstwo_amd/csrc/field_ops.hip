@@ -278,7 +278,12 @@ int tstwo_m31_sub(const u32 *a, const u32 *b, u32 *out, size_t n) { return launc
 int tstwo_m31_mul(const u32 *a, const u32 *b, u32 *out, size_t n) { return launch_binop<OP_MUL>(a, b, out, n); }
 int tstwo_m31_neg(const u32 *a, u32 *out, size_t n) { return launch_binop<OP_NEG>(a, nullptr, out, n); }
 
-int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
+int tstwo_check_zero_flag(void) {
+    TSTWO_REQUIRE_READY();
+    return finish_inverse();
+}
+
+int tstwo_m31_batch_inverse_async(const u32 *in, u32 *out, size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
     TSTWO_REQUIRE_PTRS(in, out);
@@ -293,9 +298,13 @@ int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
         hipLaunchKernelGGL(k_m31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, in, out, n, T, ctx().flag);
     }
     TSTWO_LAUNCH_CHECK();
-    return finish_inverse();
+    return TSTWO_OK;
 }
-int tstwo_cm31_batch_inverse(const u32 *const in[2], u32 *const out[2], size_t n) {
+int tstwo_m31_batch_inverse(const u32 *in, u32 *out, size_t n) {
+    int rc = tstwo_m31_batch_inverse_async(in, out, n);
+    return rc || n == 0 ? rc : finish_inverse();
+}
+int tstwo_cm31_batch_inverse_async(const u32 *const in[2], u32 *const out[2], size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
     TSTWO_REQUIRE_TABLE(in, 2); TSTWO_REQUIRE_TABLE(out, 2);
@@ -305,9 +314,13 @@ int tstwo_cm31_batch_inverse(const u32 *const in[2], u32 *const out[2], size_t n
     Soa2 o2 = {{out[0], out[1]}};
     hipLaunchKernelGGL(k_cm31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i2, o2, n, T, ctx().flag);
     TSTWO_LAUNCH_CHECK();
-    return finish_inverse();
+    return TSTWO_OK;
 }
-int tstwo_qm31_batch_inverse(const u32 *const in[4], u32 *const out[4], size_t n) {
+int tstwo_cm31_batch_inverse(const u32 *const in[2], u32 *const out[2], size_t n) {
+    int rc = tstwo_cm31_batch_inverse_async(in, out, n);
+    return rc || n == 0 ? rc : finish_inverse();
+}
+int tstwo_qm31_batch_inverse_async(const u32 *const in[4], u32 *const out[4], size_t n) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return TSTWO_OK;
     TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4);
@@ -317,7 +330,11 @@ int tstwo_qm31_batch_inverse(const u32 *const in[4], u32 *const out[4], size_t n
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
     hipLaunchKernelGGL(k_qm31_batch_inverse<K>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i4, o4, n, T, ctx().flag);
     TSTWO_LAUNCH_CHECK();
-    return finish_inverse();
+    return TSTWO_OK;
+}
+int tstwo_qm31_batch_inverse(const u32 *const in[4], u32 *const out[4], size_t n) {
+    int rc = tstwo_qm31_batch_inverse_async(in, out, n);
+    return rc || n == 0 ? rc : finish_inverse();
 }
 
 int tstwo_qm31_mul(const u32 *const a[4], const u32 *const b[4], u32 *const out[4], size_t n) {
@@ -375,7 +392,7 @@ int tstwo_twiddles_build(u32 coset_initial, u32 log_size, u32 *tw, u32 *itw) {
     hipLaunchKernelGGL(k_twiddles, dim3(ceil_div(n, 256)), dim3(256), 0, ctx().stream, coset_initial & 0x7fffffffu,
                        log_size, tw, ctx().gen_pow2);
     TSTWO_LAUNCH_CHECK();
-    if (itw) return tstwo_m31_batch_inverse(tw, itw, n);   // backend/cpu/circle.ts:223-239
+    if (itw) return tstwo_m31_batch_inverse(tw, itw, n);   // backend/cpu/circle.ts:223-239 ("0 has no inverse" for cosets through x = 0)
     return TSTWO_OK;
 }
 

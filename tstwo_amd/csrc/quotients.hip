@@ -141,13 +141,23 @@ cm31 c_from(const u32 *w) { return {w[0], w[1]}; }
 
 extern "C" {
 
-int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
-                               const u32 *batch_off, const u32 *col_idx, const u32 *abc, const u32 *batch_coeff,
-                               const u32 *prx, const u32 *pry, const u32 *pix, const u32 *piy, u32 *const out[4]) {
+// batch_off is caller data that sizes host buffers: it must start at 0 and never decrease
+static int check_batch_off(const u32 *batch_off, size_t n_batches) {
+    if (!n_batches) return TSTWO_OK;
+    if (batch_off[0] != 0) return set_error(TSTWO_ERR_BAD_ARG, "quotients: batch_off[0] must be 0");
+    for (size_t b = 0; b < n_batches; b++)
+        if (batch_off[b] > batch_off[b + 1]) return set_error(TSTWO_ERR_BAD_ARG, "quotients: batch_off must be non-decreasing");
+    return TSTWO_OK;
+}
+
+int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
+                                     const u32 *batch_off, const u32 *col_idx, const u32 *abc, const u32 *batch_coeff,
+                                     const u32 *prx, const u32 *pry, const u32 *pix, const u32 *piy, u32 *const out[4]) {
     TSTWO_REQUIRE_READY();
     if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "quotients: log size out of range");
     TSTWO_REQUIRE_TABLE(cols, n_cols); TSTWO_REQUIRE_TABLE(out, 4);
     if (n_batches) TSTWO_REQUIRE_PTRS(batch_off, col_idx, abc, batch_coeff, prx, pry, pix, piy);
+    { int rc_off = check_batch_off(batch_off, n_batches); if (rc_off) return rc_off; }
     Context &c = ctx();
     const size_t n_entries = n_batches ? batch_off[n_batches] : 0;
     for (size_t j = 0; j < n_entries; j++)
@@ -205,11 +215,14 @@ int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const 
                            d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_pow2, c.flag);
     }
     TSTWO_LAUNCH_CHECK();
-    u32 flag = 0;
-    rc = read_and_clear_flag(&flag);
-    if (rc) return rc;
-    if (flag) return set_error(TSTWO_ERR_ZERO_INVERSE, "0 has no inverse");
     return TSTWO_OK;
+}
+int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
+                               const u32 *batch_off, const u32 *col_idx, const u32 *abc, const u32 *batch_coeff,
+                               const u32 *prx, const u32 *pry, const u32 *pix, const u32 *piy, u32 *const out[4]) {
+    int rc = tstwo_quotients_accumulate_async(half_initial, log_size, cols, n_cols, n_batches, batch_off, col_idx, abc, batch_coeff,
+                                              prx, pry, pix, piy, out);
+    return rc ? rc : tstwo_check_zero_flag();
 }
 
 
@@ -219,11 +232,12 @@ int tstwo_quotients_accumulate(u32 half_initial, u32 log_size, const u32 *const 
 // the library — a few QM31 multiplications per sampled column — and handed to tstwo_quotients_accumulate.
 // points: 8 words per batch (x then y, QM31 each); values: 4 words per entry, entries of batch b are
 // [batch_off[b], batch_off[b+1]).
-int tstwo_quotients_accumulate_samples(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
-                                       const u32 *batch_off, const u32 *col_idx, const u32 *points, const u32 *values,
-                                       const u32 random_coeff[4], u32 *const out[4]) {
+static int quotients_from_samples(bool async, u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
+                                  const u32 *batch_off, const u32 *col_idx, const u32 *points, const u32 *values,
+                                  const u32 random_coeff[4], u32 *const out[4]) {
     TSTWO_REQUIRE_READY();
     if (n_batches) TSTWO_REQUIRE_PTRS(batch_off, col_idx, points, values, random_coeff);
+    { int rc_off = check_batch_off(batch_off, n_batches); if (rc_off) return rc_off; }
     const size_t n_entries = n_batches ? batch_off[n_batches] : 0;
     auto load = [](const u32 *p) { host::Q q; for (int k = 0; k < 4; k++) q.v[k] = p[k]; return q; };
     auto conj = [](host::Q q) { q.v[2] = host::neg(q.v[2]); q.v[3] = host::neg(q.v[3]); return q; };   // (c0, -c1)
@@ -251,8 +265,21 @@ int tstwo_quotients_accumulate_samples(u32 half_initial, u32 log_size, const u32
         prx[2 * b] = px.v[0]; prx[2 * b + 1] = px.v[1]; pix[2 * b] = px.v[2]; pix[2 * b + 1] = px.v[3];
         pry[2 * b] = py.v[0]; pry[2 * b + 1] = py.v[1]; piy[2 * b] = py.v[2]; piy[2 * b + 1] = py.v[3];
     }
-    return tstwo_quotients_accumulate(half_initial, log_size, cols, n_cols, n_batches, batch_off, col_idx, abc.data(), bco.data(),
-                                      prx.data(), pry.data(), pix.data(), piy.data(), out);
+    return (async ? tstwo_quotients_accumulate_async : tstwo_quotients_accumulate)(
+        half_initial, log_size, cols, n_cols, n_batches, batch_off, col_idx, abc.data(), bco.data(), prx.data(), pry.data(),
+        pix.data(), piy.data(), out);
+}
+int tstwo_quotients_accumulate_samples(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
+                                       const u32 *batch_off, const u32 *col_idx, const u32 *points, const u32 *values,
+                                       const u32 random_coeff[4], u32 *const out[4]) {
+    return quotients_from_samples(false, half_initial, log_size, cols, n_cols, n_batches, batch_off, col_idx, points, values,
+                                  random_coeff, out);
+}
+int tstwo_quotients_accumulate_samples_async(u32 half_initial, u32 log_size, const u32 *const *cols, size_t n_cols, size_t n_batches,
+                                             const u32 *batch_off, const u32 *col_idx, const u32 *points, const u32 *values,
+                                             const u32 random_coeff[4], u32 *const out[4]) {
+    return quotients_from_samples(true, half_initial, log_size, cols, n_cols, n_batches, batch_off, col_idx, points, values,
+                                  random_coeff, out);
 }
 
 }  // extern "C"
