@@ -174,6 +174,18 @@ void probe_env() {          // TSTWO_ALLOC=pool|direct|async, TSTWO_NO_POOL=1 (=
     const char *p = getenv("TSTWO_POISON");
     g_pool.poison = p && *p && strcmp(p, "0") != 0;
 }
+// HIP's stream-ordered pool: keep freed blocks mapped (release threshold = max) unless TSTWO_ASYNC_RELEASE=1 asks for HIP's
+// default (threshold 0: every synchronisation unmaps the free blocks and the next hipMallocAsync maps the range again).
+// With the default, kernels launched after such a re-map were observed to access other memory than the copy engines
+// (tools/diag_async_alloc.py): columns read back as uploaded, untouched by the transform that "ran" on them.
+int configure_async_pool() {
+    hipMemPool_t pool = nullptr;
+    TSTWO_HIP(hipDeviceGetDefaultMemPool(&pool, g_ctx.device));
+    const char *r = getenv("TSTWO_ASYNC_RELEASE");
+    uint64_t threshold = (r && *r && strcmp(r, "0") != 0) ? 0 : UINT64_MAX;
+    TSTWO_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold));
+    return TSTWO_OK;
+}
 int trim_locked() {
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
     for (auto &kv : g_pool.free_lists)
@@ -343,6 +355,7 @@ int tstwo_set_alloc_mode(int mode) {
     if (rc) return rc;
     g_pool.mode = base;
     g_pool.poison = (mode & TSTWO_ALLOC_POISON) != 0;
+    if (base == TSTWO_ALLOC_ASYNC) return configure_async_pool();
     return TSTWO_OK;
 }
 
@@ -351,7 +364,10 @@ int tstwo_malloc(void **dev, size_t bytes) {
     if (!dev) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_malloc: null out pointer");
     *dev = nullptr;
     std::lock_guard<std::mutex> lock(g_pool.mu);
-    probe_env();
+    if (!g_pool.probed) {
+        probe_env();
+        if (g_pool.mode == TSTWO_ALLOC_ASYNC) { int rc_cfg = configure_async_pool(); if (rc_cfg) return rc_cfg; }
+    }
     if (bytes == 0) bytes = 16;
     const int mode = g_pool.mode;
     const size_t cls = mode == TSTWO_ALLOC_POOL ? size_class(bytes) : bytes;
