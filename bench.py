@@ -136,41 +136,36 @@ def main():
     n, n_cols = args.log_size, args.cols
     N = 1 << n
 
-    # torch is plumbing only (RCCL all-gather of roots, barrier).  It must be imported BEFORE the HIP library is
-    # dlopen'ed so that both bind the same HIP runtime (same soname) in this process.
+    # torch.distributed is control plane only (rendezvous, barrier, max-reduce of the elapsed time, hand-over of the RCCL
+    # unique id) on the gloo backend; the one collective on the data path — the all-gather of Merkle roots — is RCCL
+    # over xGMI issued through the library's own C ABI (tstwo_comm_init / tstwo_allgather_async), exactly what a Bun
+    # host would call.  TSTWO_BENCH_COLLECTIVE=gloo rehearses the N > 1 control flow on a one-GPU box (all ranks share
+    # GPU 0, where RCCL refuses several ranks per device): roots then travel through host memory.
     import torch
     import torch.distributed as dist
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)
-    torch.cuda.set_device(dev_index)
-    # "nccl" (= RCCL over xGMI) is the product path; TSTWO_DIST_BACKEND=gloo lets the N > 1 code path be rehearsed on a
-    # one-GPU box (all ranks share GPU 0, roots travel through host memory).
-    backend_name = os.environ.get("TSTWO_DIST_BACKEND", "nccl")
+    collective = os.environ.get("TSTWO_BENCH_COLLECTIVE", "rccl")
     use_dist = world > 1 or bool(os.environ.get("TSTWO_FORCE_DIST"))   # FORCE: rehearse the collective path at world size 1
     if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend_name == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend_name, rank=rank, world_size=world)
-    root_dev = "cuda" if backend_name == "nccl" else "cpu"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from tstwo_amd import _lib as L
     from tstwo_amd.backend import HipBackend, shard_columns
 
     L.init(dev_index)
-    side_stream = None
-    if use_dist and backend_name == "nccl":
-        # One explicit stream shared by torch and the library: copy-root -> all-gather -> next step are then ordered on it,
-        # with no host sync per step.  (torch's default stream is the NULL stream; the library's own stream is non-blocking
-        # and does not synchronise with it, so the default stream must not be what RCCL orders against.)
-        side_stream = torch.cuda.Stream(device=dev_index)
-        torch.cuda.set_stream(side_stream)
-        L.call("tstwo_set_stream", C.c_void_p(side_stream.cuda_stream))
+    if use_dist and collective == "rccl":
+        ids = [None]
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            L.call("tstwo_comm_unique_id", buf)
+            ids[0] = bytes(buf)
+        dist.broadcast_object_list(ids, src=0)
+        L.call("tstwo_comm_init", rank, world, (C.c_uint8 * 128).from_buffer_copy(ids[0]))
     backend = HipBackend()
 
     # ---- the rank's shard of the (world * n_cols) trace columns, resident in HBM
@@ -186,11 +181,11 @@ def main():
     L.call("tstwo_twiddles_build", half_initial, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
     layers = L.DeviceBuffer(32 * ((2 << n) - 1))
     log_sizes = L.u32x([n] * n_cols)
-    # two root slots: the all-gather of step k (async on RCCL's stream) overlaps the CFFT of step k+1, so slot k%2 is
-    # rewritten only after the collective that read it (step k-2's... see `pending`) has been waited for
-    roots_local = [torch.zeros(32, dtype=torch.uint8, device=root_dev) for _ in range(2)]
-    roots_all = [torch.zeros(32 * world, dtype=torch.uint8, device=root_dev) for _ in range(2)]
-    pending = [None, None]
+    # two root slots; the all-gather of step k runs on the library's collective stream and overlaps the CFFT of step k+1
+    # (tstwo_comm_wait at the next issue point makes the main stream wait for it on the device, never the host)
+    root_slot = [L.DeviceBuffer(32) for _ in range(2)]
+    roots_all = [L.DeviceBuffer(32 * world) for _ in range(2)]
+    roots_host = [np.zeros(32 * world, dtype=np.uint8) for _ in range(2)]
     step_no = [0]
     L.sync()
 
@@ -209,29 +204,30 @@ def main():
         if use_dist:   # the only exchange on the path: 32-byte roots over RCCL/xGMI
             k = step_no[0] & 1
             step_no[0] += 1
-            if pending[k] is not None:
-                pending[k].wait()          # stream-side wait (nccl) / host wait (gloo) for the collective that used slot k
-            if root_dev == "cuda":
-                L.call("tstwo_copy", C.c_void_p(roots_local[k].data_ptr()), C.c_void_p(layers.ptr), 32)
-            else:
-                L.call("tstwo_download", C.c_void_p(roots_local[k].data_ptr()), C.c_void_p(layers.ptr), 32)
-            pending[k] = dist.all_gather_into_tensor(roots_all[k], roots_local[k], async_op=True)
+            if collective == "rccl":
+                L.call("tstwo_comm_wait")                  # the previous step's collective (it had this whole step to finish)
+                L.call("tstwo_copy", C.c_void_p(root_slot[k].ptr), C.c_void_p(layers.ptr), 32)
+                L.call("tstwo_allgather_async", C.c_void_p(root_slot[k].ptr), C.c_void_p(roots_all[k].ptr), 32)
+            else:                                           # rehearsal: host round trip + gloo
+                mine = torch.from_numpy(layers.download(np.uint8, 32).copy())
+                out = torch.from_numpy(roots_host[k])
+                dist.all_gather_into_tensor(out, mine)
 
     def drain():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        if collective == "rccl":
+            L.call("tstwo_comm_wait")
 
     def barrier():
         if use_dist:
             drain()
         L.sync()
-        torch.cuda.synchronize()
+        if n_dev:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         L.sync()
-        torch.cuda.synchronize()
+        if n_dev:
+            torch.cuda.synchronize()
 
     # Correctness of the measured workload: the first (untimed) step runs on the fresh synthetic input; its root is
     # compared below with the CPU oracle's root of the same 32 x 2^22 columns (cpu_baseline.root) -> "root_match".
@@ -249,13 +245,16 @@ def main():
     t_merkle = sum(e[1].elapsed_ms(e[2]) for e in evs)
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=root_dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # roots of all ranks must have arrived and rank r's slot must hold rank r's root
+        # every rank's root must have arrived in rank order: compare the RCCL result with a gloo all-gather of the same roots
         last = (step_no[0] - 1) & 1
-        mine = bytes(roots_all[last][32 * rank:32 * rank + 32].cpu().numpy().tobytes())
-        assert mine == bytes(layers.download(np.uint8, 32).tobytes())
+        got = roots_all[last].download(np.uint8, 32 * world) if collective == "rccl" else roots_host[last]
+        mine = torch.from_numpy(layers.download(np.uint8, 32).copy())
+        ref = torch.zeros(32 * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(ref, mine)
+        assert bytes(got.tobytes()) == bytes(ref.numpy().tobytes()), "all-gathered roots differ from the ranks' own roots"
 
     if rank == 0:
         steps = args.steps
@@ -291,7 +290,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 5 shard: {n_cols} columns x 2^{n} per GPU "
                                    f"({world * n_cols} columns total), CircleDomain of CanonicCoset({n}); "
-                                   "evaluate + per-GPU Merkle tree" + (" + RCCL all-gather of roots" if world > 1 else ""),
+                                   "evaluate + per-GPU Merkle tree" + (" + RCCL all-gather of roots (C ABI: tstwo_allgather_async)" if world > 1 else ""),
                        "log_size": n, "columns_per_gpu": n_cols, "parallelism": f"column-shard x{world}"},
             "cfft_ms": cfft_ms,
             "cfft_butterflies_per_s": n_cols * n * (N // 2) / (cfft_ms * 1e-3),
@@ -330,6 +329,8 @@ def main():
 
     if use_dist:
         dist.barrier()
+        if collective == "rccl":
+            L.call("tstwo_comm_destroy")
         dist.destroy_process_group()
 
 

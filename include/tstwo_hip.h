@@ -43,6 +43,7 @@ extern "C" {
 #define TSTWO_ERR_LEN_MISMATCH 6   /* "fold_circle_into_line: Length mismatch ..." fri.ts:168 */
 #define TSTWO_ERR_BAD_ARG 7
 #define TSTWO_ERR_LOG_SIZE 8       /* "log size too small"                    backend/cpu/circle.ts:72 */
+#define TSTWO_ERR_COMM 9           /* RCCL missing or failing (text has the ncclResult string) */
 
 /* ---------------------------------------------------------------- lifecycle / plumbing */
 int tstwo_init(int device);                 /* select GPU `device`, create the stream; idempotent */
@@ -284,6 +285,31 @@ int tstwo_quotients_accumulate_samples_async(uint32_t half_initial, uint32_t log
                                              size_t n_cols, size_t n_batches, const uint32_t *batch_off,
                                              const uint32_t *col_idx, const uint32_t *points, const uint32_t *values,
                                              const uint32_t random_coeff[4], uint32_t *const out[4]);
+
+/* ---------------------------------------------------------------- multi-GPU: the one exchange on the path
+ * Column sharding: rank g commits its own Merkle tree over its own trace columns and the ranks all-gather the
+ * 32-byte roots, which every rank then mixes into its channel in rank order (TreeVec order; pcs/prover.ts:62-64,227-228).
+ * One process per GPU; the collective is RCCL's ncclAllGather over xGMI, enqueued on the library's stream behind the
+ * kernels that produce the root (asynchronous: no host synchronisation).  RCCL is bound at run time (dlopen), so
+ * single-GPU hosts need no librccl.
+ *   rank 0: tstwo_comm_unique_id(id); the 128 bytes travel to the other ranks by any host channel (file, socket, env);
+ *   every rank: tstwo_comm_init(rank, world, id)        — collective, returns when all ranks have joined;
+ *   per commit: tstwo_allgather_roots(layers (byte 0 = root), roots_out (world * 32 bytes, device)).
+ * Without a communicator (a world of one) the gathers degenerate to a device copy.  tstwo_allgather moves any small
+ * per-rank record the same way (the subtree roots of a row-sharded FRI layer). */
+#define TSTWO_COMM_ID_BYTES 128
+int tstwo_comm_unique_id(uint8_t id[TSTWO_COMM_ID_BYTES]);
+int tstwo_comm_init(int rank, int world, const uint8_t id[TSTWO_COMM_ID_BYTES]);
+int tstwo_comm_destroy(void);
+int tstwo_comm_info(int *rank, int *world);
+int tstwo_allgather_roots(const uint8_t *root_dev, uint8_t *roots_out_dev);
+int tstwo_allgather(const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+/* Overlapped form: the collective runs on a second stream of the library, behind everything enqueued so far, while later
+ * calls (the next commit's CFFT) proceed on the main stream.  Neither buffer may be touched by later work until
+ * tstwo_comm_wait() has been called: it makes the main stream wait (on the device, not the host) for the last async
+ * collective; tstwo_sync() after it covers both. */
+int tstwo_allgather_async(const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+int tstwo_comm_wait(void);
 
 #ifdef __cplusplus
 }

@@ -1157,3 +1157,32 @@ def test_merkle_decommit_many_equals_individual_calls():
         assert dec.hashWitness == dec1.hashWitness and [v.value for v in dec.columnWitness] == [v.value for v in dec1.columnWitness]
         T.MerkleVerifier(T.Blake2sMerkleHasher, tree.root(), [c.len().bit_length() - 1 for c in cols]).verify(queries, qv, dec)
     assert T.MerkleProver.decommit_many([]) == []
+
+
+def test_c_abi_collective_world_of_one():
+    """include/tstwo_hip.h "multi-GPU": the RCCL communicator behind the C ABI.  This pool gives one GPU, so the world has
+    one rank (RCCL initialises, the all-gather returns the own root); N > 1 over xGMI is covered by bench.py --gpus N
+    only.  Also: without a communicator the gathers are device copies, and the async form orders against the stream."""
+    import ctypes as C
+    from tstwo_amd.distributed import HipComm
+    cols = [T.HipColumn(rand_column(900 + c, 1 << 10)) for c in range(5)]
+    tree = T.MerkleProver.commit(cols)
+    root = tree.root()
+    out = L.DeviceBuffer(32)
+    L.call("tstwo_allgather_roots", C.c_void_p(tree.root_ptr()), C.c_void_p(out.ptr))         # no communicator: copy
+    assert out.download(np.uint8, 32).tobytes() == root
+    comm = HipComm(0, 1, lambda uid: uid)
+    try:
+        r, w = C.c_int(-1), C.c_int(-1)
+        L.call("tstwo_comm_info", C.byref(r), C.byref(w))
+        assert (r.value, w.value) == (0, 1)
+        assert comm.allgather_roots(tree.root_ptr()) == [root]
+        out2 = L.DeviceBuffer(32)
+        out2.zero()
+        L.call("tstwo_allgather_async", C.c_void_p(tree.root_ptr()), C.c_void_p(out2.ptr), 32)
+        L.call("tstwo_comm_wait")
+        assert out2.download(np.uint8, 32).tobytes() == root
+        with pytest.raises(L.TstwoError, match="already initialised"):
+            HipComm(0, 1, lambda uid: uid)
+    finally:
+        comm.close()

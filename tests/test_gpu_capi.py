@@ -179,6 +179,24 @@ def test_cfft_vs_oracle(n):
     assert (host(dv[0], 1 << n) == orc.cfft_interpolate(vals, n, half_odds(n - 1), oitw, tw_log)).all()
 
 
+@pytest.mark.parametrize("n", [14, 15, 16, 17, 18, 19, 20, 21])
+def test_cfft_many_columns_default_tiles(n):
+    """Enough columns that the transform takes the default tiles (2^13 contiguous + 2^14 strided, every K from 1 to 8) rather
+    than the small tiles chosen for few columns; both directions against the oracle (threaded driver)."""
+    n_cols = max(3, (2 * 256 + 1) >> (n - 14)) + 1
+    tw, itw = build_twiddles(n - 1)
+    otw, oitw = orc.precompute_twiddles(half_odds(n - 1), n - 1)
+    cols = [rand_column(1000 * n + c, 1 << n) for c in range(n_cols)]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_cfft_evaluate", ptrs(d), n_cols, n, half_odds(n - 1), vp(tw), n - 1)
+    exp = orc.mt_cfft_evaluate([c.copy() for c in cols], n, half_odds(n - 1), otw, n - 1, 16)
+    for c in range(n_cols):
+        assert (host(d[c], 1 << n) == exp[c]).all(), f"evaluate log {n} col {c} of {n_cols}"
+    L.call("tstwo_cfft_interpolate", ptrs(d), n_cols, n, half_odds(n - 1), vp(itw), n - 1)
+    for c in range(n_cols):
+        assert (host(d[c], 1 << n) == cols[c]).all(), f"interpolate log {n} col {c} of {n_cols}"
+
+
 def test_cfft_golden(golden):
     for e in golden["cfft"]:
         n = e["log"]

@@ -59,7 +59,7 @@ constexpr int ITERS = 2048;
 #define I_MINS(d) "v_min_u32 " d ", %10, " d "\n"
 #define I_MULLOS(d) "v_mul_lo_u32 " d ", " d ", %10\n"
 ASM_KERNEL(k_add, I_ADD) ASM_KERNEL(k_sub, I_SUB) ASM_KERNEL(k_min, I_MIN) ASM_KERNEL(k_xor, I_XOR) ASM_KERNEL(k_and, I_AND)
-ASM_KERNEL(k_mov, I_MOV) ASM_KERNEL(k_lshr, I_LSHR) ASM_KERNEL(k_add3, I_ADD3) ASM_KERNEL(k_xor3, I_XOR3)
+ASM_KERNEL(k_mov, I_MOV) ASM_KERNEL(k_lshr, I_LSHR) ASM_KERNEL(k_add3, I_ADD3)
 ASM_KERNEL(k_lshladd, I_LSHLADD) ASM_KERNEL(k_addlshl, I_ADDLSHL) ASM_KERNEL(k_andor, I_ANDOR) ASM_KERNEL(k_bfi, I_BFI)
 ASM_KERNEL(k_bfe, I_BFE) ASM_KERNEL(k_perm, I_PERM) ASM_KERNEL(k_alignbit, I_ALIGNBIT) ASM_KERNEL(k_mullo, I_MULLO)
 ASM_KERNEL(k_mulhi, I_MULHI) ASM_KERNEL(k_mul24, I_MUL24) ASM_KERNEL(k_mad24, I_MAD24) ASM_KERNEL(k_fma, I_FMA)
@@ -115,6 +115,34 @@ __global__ void __launch_bounds__(256) k_bf16(u32 *out, u32 seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// the same with the modulus in an (opaque) VGPR instead of a literal: the s - P / d + P become VGPR-VGPR VOP2 (double rate)
+__device__ __forceinline__ void bf_dbl_v(u32 &v0, u32 &v1, u32 t2, u32 P) {
+    u64 p = (u64)v1 * (u64)t2;
+    u32 s = (u32)(p >> 32) + ((u32)p >> 1);
+    u32 m = min(s, s - P);
+    u32 a = v0 + m, d = v0 - m;
+    v0 = min(a, a - P);
+    v1 = min(d, d + P);
+}
+__global__ void __launch_bounds__(256) k_bf16v(u32 *out, u32 seed) {
+    u32 v[16];
+    for (int j = 0; j < 16; j++) v[j] = ((threadIdx.x + seed) * (2 * j + 3)) % 2147483647u;
+    u32 t = ((seed * 2654435761u) % 2147483647u) * 2;
+    u32 P = 2147483647u;
+    asm("" : "+v"(P));
+#pragma unroll 1
+    for (int i = 0; i < ITERS / 4; i++) {
+#pragma unroll
+        for (int l = 3; l >= 0; l--)
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                if (!(m & (1 << l))) bf_dbl_v(v[m], v[m | (1 << l)], t + l, P);
+    }
+    u32 r = 0;
+    for (int j = 0; j < 16; j++) r ^= v[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 typedef void (*kern_t)(u32 *, u32);
 struct Entry { const char *name; kern_t k; double ops_per_iter; };
 
@@ -146,7 +174,7 @@ int main() {
     CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
     Entry es[] = {
         {"v_add_u32", k_add, 32}, {"v_sub_u32", k_sub, 32}, {"v_min_u32", k_min, 32}, {"v_xor_b32", k_xor, 32}, {"v_and_b32", k_and, 32},
-        {"v_mov_b32", k_mov, 32}, {"v_lshrrev_b32", k_lshr, 32}, {"v_add3_u32", k_add3, 32}, {"v_xor3_b32", k_xor3, 32},
+        {"v_mov_b32", k_mov, 32}, {"v_lshrrev_b32", k_lshr, 32}, {"v_add3_u32", k_add3, 32},
         {"v_lshl_add_u32", k_lshladd, 32}, {"v_add_lshl_u32", k_addlshl, 32}, {"v_and_or_b32", k_andor, 32}, {"v_bfi_b32", k_bfi, 32},
         {"v_bfe_u32", k_bfe, 32}, {"v_perm_b32", k_perm, 32}, {"v_alignbit_b32", k_alignbit, 32}, {"v_mul_lo_u32", k_mullo, 32},
         {"v_mul_hi_u32", k_mulhi, 32}, {"v_mul_u32_u24", k_mul24, 32}, {"v_mad_u32_u24", k_mad24, 32}, {"v_fma_f32", k_fma, 32},
@@ -154,6 +182,7 @@ int main() {
         {"v_add_u32_sgpr", k_adds, 32}, {"v_min_u32_sgpr", k_mins, 32}, {"v_mul_lo_u32_sgpr", k_mullos, 32},
         {"v_mad_u64_u32", k_mad64, 32}, {"v_mad_u64_u32_sgpr", k_mad64s, 32}, {"v_mad_u64_u32_zero_addend", k_mad64z, 32},
         {"m31_butterfly_compiled(11 instr)", k_bf16, 32.0 / 4},   // 32 butterflies per 4 ITERS-units
+        {"m31_butterfly_compiled_P_in_vgpr", k_bf16v, 32.0 / 4},
     };
     // warm up clocks
     for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_add, dim3(cus * 8), dim3(256), 0, 0, out, 1u);

@@ -32,6 +32,14 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_download: { args: [P, u64, u64], returns: i32 },
   tstwo_copy: { args: [u64, u64, u64], returns: i32 },
   tstwo_zero: { args: [u64, u64], returns: i32 },
+  tstwo_comm_unique_id: { args: [P], returns: i32 },
+  tstwo_comm_init: { args: [i32, i32, P], returns: i32 },
+  tstwo_comm_destroy: { args: [], returns: i32 },
+  tstwo_comm_info: { args: [P, P], returns: i32 },
+  tstwo_allgather_roots: { args: [u64, u64], returns: i32 },
+  tstwo_allgather: { args: [u64, u64, u64], returns: i32 },
+  tstwo_allgather_async: { args: [u64, u64, u64], returns: i32 },
+  tstwo_comm_wait: { args: [], returns: i32 },
   tstwo_m31_add: { args: [u64, u64, u64, u64], returns: i32 },
   tstwo_m31_sub: { args: [u64, u64, u64, u64], returns: i32 },
   tstwo_m31_mul: { args: [u64, u64, u64, u64], returns: i32 },

@@ -59,6 +59,14 @@ _SIGS = {
     "tstwo_event_record": [vp],
     "tstwo_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
     "tstwo_event_destroy": [vp],
+    "tstwo_comm_unique_id": [u8p],
+    "tstwo_comm_init": [C.c_int, C.c_int, u8p],
+    "tstwo_comm_destroy": [],
+    "tstwo_comm_info": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "tstwo_allgather_roots": [vp, vp],
+    "tstwo_allgather": [vp, vp, C.c_size_t],
+    "tstwo_allgather_async": [vp, vp, C.c_size_t],
+    "tstwo_comm_wait": [],
     "tstwo_m31_add": [vp, vp, vp, C.c_size_t],
     "tstwo_m31_sub": [vp, vp, vp, C.c_size_t],
     "tstwo_m31_mul": [vp, vp, vp, C.c_size_t],

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libtstwo_hip.so")
-SOURCES = ["context.hip", "field_ops.hip", "cfft.hip", "fri.hip", "merkle.hip", "quotients.hip"]
+SOURCES = ["context.hip", "field_ops.hip", "cfft.hip", "fri.hip", "merkle.hip", "quotients.hip", "comm.hip"]
 HEADERS = ["common.h", "m31.cuh", "host_field.h", "cfft_fast.cuh", os.path.join("..", "..", "include", "tstwo_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
@@ -53,10 +53,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(7, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), SOURCES))
     if force or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -21,6 +21,7 @@
 //
 // Algorithmic bytes: 8 per element per transform (column read once + written once); real HBM/MALL
 // traffic: 8 per element per pass (+ <= 2 for twiddles).  DESIGN.md §CFFT has the roofline numbers.
+#include <unordered_map>
 #include <unordered_set>
 
 #include "common.h"
@@ -53,6 +54,9 @@ __device__ __forceinline__ u32 phys(u32 e) { return e + (e >> 5); }
 // x * t for a twiddle stored doubled (t2 = 2t < 2^32): the 64-bit product's high word is
 // floor(x t / 2^31) and its low word >> 1 is (x t) mod 2^31, so the Mersenne fold needs no
 // and/alignbit (stwo's SIMD backend keeps "dbl" twiddles for the same reason).
+// (Keeping P in a VGPR so that s - P / d + P become VGPR-VGPR VOP2 does not pay: the pure add / sub streams of
+// tools/microbench2.hip issue at twice the rate of the literal forms, but inside the butterfly's mixed stream the
+// 11 instructions take the same 44 cycles either way — profiles/r02_microbench.json, both butterfly rows.)
 __device__ __forceinline__ u32 m31_mul_dbl(u32 x, u32 t2) {
     u64 p = (u64)x * (u64)t2;
     u32 s = (u32)(p >> 32) + ((u32)p >> 1);
@@ -288,7 +292,7 @@ __global__ void k_cfft_small(ColPtrs cols, u32 n_cols, u32 n, u32 tx, u32 ty, u3
 
 struct Pass { u32 lo, k, c; };
 // passes low -> high.  kb = layers of the bottom pass (contiguous tile), the rest is cut into strided passes of <= ka_max.
-int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA) {
+int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA, u32 logta = kLogTileA) {
     int cnt = 0;
     if (n <= kb) {
         out[cnt++] = {0, n, 0};
@@ -300,7 +304,7 @@ int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA) {
     u32 base = rem / np, extra = rem % np;
     for (u32 s = 0; s < np; s++) {
         u32 k = base + (s < extra ? 1 : 0);
-        u32 c = kLogTileA - k;
+        u32 c = logta - k;
         if (c > lo) c = lo;
         out[cnt++] = {lo, k, c};
         lo += k;
@@ -350,16 +354,29 @@ int launch_pass(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
     return launch_pass_t<INV, kThreadsA>(cols, n_cols, pp);
 }
 
-u32 pick_cols_per_wg(size_t tiles, size_t cnt) {
-    // columns per workgroup: amortise the twiddle staging, but keep >= ~8 workgroups per CU in the grid
-    // (measured 32 x 2^22: 747 / 703 / 678 / 671 / 672 us for 1 / 2 / 4 / 8 / 16 columns per workgroup)
-    u32 cpw = 8;
-    const char *e = getenv("TSTWO_CFFT_CPW");            // debugging / tuning override, taken as is
-    if (e && atoi(e) > 0) cpw = (u32)atoi(e);
-    else
-        while (cpw > 1 && tiles * ((cnt + cpw - 1) / cpw) < (size_t)ctx().n_cus * 8) cpw >>= 1;
-    if (cpw > cnt) cpw = (u32)cnt;
-    return cpw;
+// Grid of a pass kernel: its (tile, column) work items are dealt in equal contiguous shares to as many workgroups as the
+// chip holds at once (CUs x resident workgroups per CU for this kernel's registers / LDS), so the whole pass is ONE round of
+// workgroups with no tail round and each workgroup stages a tile's twiddles once for all of its columns of that tile.
+// (32 x 2^22: 2048 workgroups of 8 columns on 768 resident slots made 2.67 rounds, i.e. 11 % of the slots idle in the last
+// one, and paid the twiddle / first-load prologue 2048 times instead of 768.)  TSTWO_CFFT_ROUNDS=k asks for k x that many
+// workgroups (dynamic balance against the extra prologues); fewer items than slots: one item per workgroup.
+unsigned plan_grid(const void *kernel, int threads, size_t lds_bytes, size_t total_items) {
+    static std::unordered_map<const void *, int> resident;        // workgroups per CU, per kernel
+    auto it = resident.find(kernel);
+    if (it == resident.end()) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        it = resident.emplace(kernel, per_cu).first;
+    }
+    size_t slots = (size_t)ctx().n_cus * (size_t)it->second;
+    static const int rounds = [] { const char *e = getenv("TSTWO_CFFT_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    slots *= (size_t)rounds;
+    static const int cap = [] { const char *e = getenv("TSTWO_CFFT_MAXWG"); return e && atoi(e) > 0 ? atoi(e) : 0; }();   // experiments
+    if (cap && slots > (size_t)cap) slots = (size_t)cap;
+    return (unsigned)(total_items < slots ? total_items : slots);
 }
 
 // Tiles above 64 KiB of LDS need a per-kernel opt-in (160 KiB per CU on gfx950); done once per kernel, not per launch.
@@ -373,6 +390,10 @@ int allow_big_lds(const void *kernel) {
 template <typename KernelT, typename... Args>
 int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t tiles, u32 *const *cols, size_t n_cols, Args... args) {
     Context &c = ctx();
+    {   // experiments: extra (unused) dynamic LDS per workgroup lowers the number of resident workgroups per CU
+        static const int pad = [] { const char *e = getenv("TSTWO_CFFT_LDS_PAD"); return e ? atoi(e) : 0; }();
+        lds_bytes += (size_t)pad;
+    }
     { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
     if (getenv("TSTWO_CFFT_TRACE")) {
         hipFuncAttributes fa;
@@ -385,21 +406,22 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
         ColPtrs cp;
         int rc_tab = fill_col_table(cp, cols, n_cols, 0);
         if (rc_tab) return rc_tab;
-        const u32 cpw = pick_cols_per_wg(tiles, cnt);
-        size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
-        if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(threads), lds_bytes, c.stream, cp, (u32)cnt, cpw, args...);
+        const size_t items = tiles * cnt;
+        if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
+        const unsigned blocks = plan_grid((const void *)kernel, threads, lds_bytes, items);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, c.stream, cp, (u32)cnt, (u32)items, args...);
     }
     TSTWO_LAUNCH_CHECK();
     if (getenv("TSTWO_CFFT_SYNC")) TSTWO_HIP(hipStreamSynchronize(c.stream));
     return TSTWO_OK;
 }
 
-template <bool INV, int K>
+template <bool INV, int K, int LOGTA = 14>
 int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, u32 scale) {
-    const size_t tiles = (size_t)1 << (n - 14);
-    return launch_fast_kernel(fast::k_cfft_a<INV, K>, 1024, ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols,
-                              n, lo, tw_end, scale, fast::NoSrc{});
+    const size_t tiles = (size_t)1 << (n - LOGTA);
+    return launch_fast_kernel(fast::k_cfft_a<INV, K, 0, LOGTA>, 1 << (LOGTA - 4),
+                              ((size_t)(1 << LOGTA) + (1 << (LOGTA - 5)) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols, n, lo, tw_end, scale,
+                              fast::NoSrc{});
 }
 
 // First forward pass of an evaluation whose input is a smaller polynomial (log size n - EXT) in its own buffers.
@@ -416,10 +438,10 @@ int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, 
         int rc_tab = fill_col_table(cp, cols, n_cols, 0);
         if (!rc_tab) rc_tab = fill_col_table(sp, src, n_cols, 1);
         if (rc_tab) return rc_tab;
-        const u32 cpw = pick_cols_per_wg(tiles, cnt);
-        size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
-        if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
-        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(1024), lds_bytes, c.stream, cp, (u32)cnt, cpw, n, lo, tw_end, 0u, sp);
+        const size_t items = tiles * cnt;
+        if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
+        const unsigned blocks = plan_grid((const void *)kernel, 1024, lds_bytes, items);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, c.stream, cp, (u32)cnt, (u32)items, n, lo, tw_end, 0u, sp);
     }
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
@@ -452,6 +474,25 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
             default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported bottom pass");
         }
     }
+    const u32 logta = ps.c + ps.k;
+    if (logta == 12) {          // small strided tiles (few columns): 256 lanes, rows of 2^(12-K) >= 16 words
+        switch (ps.k) {
+            case 1: return launch_a<INV, 1, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 2: return launch_a<INV, 2, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 3: return launch_a<INV, 3, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 4: return launch_a<INV, 4, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 5: return launch_a<INV, 5, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 6: return launch_a<INV, 6, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 7: return launch_a<INV, 7, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 8: return launch_a<INV, 8, 12>(cols, n_cols, n, ps.lo, tw_end, scale);
+            default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+        }
+    }
+    if (logta == 13) {
+        if (ps.k == 9) return launch_a<INV, 9, 13>(cols, n_cols, n, ps.lo, tw_end, scale);
+        return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+    }
+    if (logta != 14) return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
     switch (ps.k) {
         case 1: return launch_a<INV, 1>(cols, n_cols, n, ps.lo, tw_end, scale);
         case 2: return launch_a<INV, 2>(cols, n_cols, n, ps.lo, tw_end, scale);
@@ -506,7 +547,27 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
         if (e1 && atoi(e1) >= 11 && atoi(e1) <= 13) kb = (u32)atoi(e1);
         if (e2 && atoi(e2) >= 1 && atoi(e2) <= 10) ka_max = (u32)atoi(e2);
     }
-    int np = n >= kMaxLogTileB ? plan_passes(n, passes, kb, ka_max) : plan_passes(n, passes);
+    u32 logta = kLogTileA;
+    if (n >= kMaxLogTileB && !getenv("TSTWO_CFFT_KB") && !getenv("TSTWO_CFFT_KA")) {
+        // Few columns: the default tiles (2^13 contiguous, 2^14 strided) give 2^(n-13) x cols and 2^(n-14) x cols workgroups;
+        // below ~2 per CU pick the split with the most workgroups in its emptier pass (ties: the larger tiles).
+        // n = 20, one column: 12 + 8 layers on 2^12-word tiles = 256 + 256 workgroups instead of 128 + 64.
+        const size_t want = (size_t)2 * (size_t)c.n_cus;
+        if ((((size_t)1 << (n - kLogTileA)) * n_cols) < want && n - 13 <= ka_max) {
+            size_t best = 0;
+            for (u32 tb = 13; tb >= 11; tb--) {
+                const u32 k = n - tb;
+                if (k < 1 || k > ka_max) continue;        // one strided pass
+                const u32 ta = k <= 8 ? 12u : (k == 9 ? 13u : 14u);
+                if (ta > n) continue;
+                size_t wa = ((size_t)1 << (n - ta)) * n_cols, wb = ((size_t)1 << (n - tb)) * n_cols;
+                size_t score = wa < wb ? wa : wb;
+                if (score > want) score = want;
+                if (score > best) { best = score; kb = tb; logta = ta; }
+            }
+        }
+    }
+    int np = n >= kMaxLogTileB ? plan_passes(n, passes, kb, ka_max, logta) : plan_passes(n, passes);
     for (size_t i = 0; i < n_cols; i++)
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
     if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
@@ -590,10 +651,10 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
                 int rc_tab = fill_col_table(cp, dst, n_cols, 0);
                 if (!rc_tab) rc_tab = fill_col_table(sp, src, n_cols, 1);
                 if (rc_tab) return rc_tab;
-                const u32 cpw = pick_cols_per_wg(tiles, cnt);
-                size_t blocks = tiles * ((cnt + cpw - 1) / cpw);
-                if (blocks > 0x7fffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: grid too large");
-                hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(512), lds, c.stream, cp, (u32)cnt, cpw, log_size, tw_end,
+                const size_t items = tiles * cnt;
+                if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
+                const unsigned blocks = plan_grid((const void *)kernel, 512, lds, items);
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, c.stream, cp, (u32)cnt, (u32)items, log_size, tw_end,
                                    np == 1 ? n_inv : 0u, sp);
             }
             TSTWO_LAUNCH_CHECK();

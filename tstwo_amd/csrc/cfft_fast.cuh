@@ -3,7 +3,7 @@
 // Geometry is compile-time so that addressing folds into immediates and the register budget stays
 // near 64 VGPRs (8 waves/SIMD): every lane owns 16 words of the tile.
 //   k_cfft_b<INV, LOGT> bottom pass: layers 0..LOGT-1 on a contiguous 2^LOGT-word tile (LOGT = 13: 512 lanes).
-//   k_cfft_a<INV, K>    strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^(14-K) words, 1024 lanes.
+//   k_cfft_a<INV, K, EXT, LOGT> strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^(LOGT-K) words, 2^(LOGT-4) lanes (LOGT = 14: 1024).
 // Structure of one tile (forward; the inverse mirrors it):
 //   1. the tile arrives as four 16-byte loads per lane a quarter-tile apart, so the pass's two top layers
 //      are a radix-4 butterfly in registers before anything touches LDS;
@@ -104,7 +104,7 @@ template <> struct SrcTable<0> { using type = NoSrc; };
 // (2^(LOGT-4) lanes).  LOGT = 13 is the default; smaller tiles give more workgroups when there are few columns.
 // OOP: tiles are read from `src` (left untouched) and written to `cols` — the first pass of an out-of-place interpolation.
 template <bool INV, int LOGT, bool OOP = false>
-__global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n,
+__global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32 n_cols, u32 total_items, u32 n,
                                                  const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<OOP ? 1 : 0>::type src) {
     constexpr int THREADS = 1 << (LOGT - 4);
     constexpr int GM = LOGT - 10;              // layers of the middle LDS stage (bits [8, LOGT-2))
@@ -112,10 +112,19 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     u32 *twl = lds + T + T / 32;                          // 2^(LOGT-4)-entry heap: layer bits 4..LOGT-3
     const u32 t = threadIdx.x;
-    const u32 groups = (n_cols + cols_per_wg - 1) / cols_per_wg;
-    const u32 hi = blockIdx.x / groups;                   // tile index
-    const u32 col0 = (blockIdx.x % groups) * cols_per_wg;
-    const u32 col1 = min(col0 + cols_per_wg, n_cols);
+    // Work items are (tile, column) pairs in tile-major order; this workgroup owns a contiguous range of them (equal shares,
+    // the grid is sized to what is resident at once: no tail round), cut below into runs of columns that share a tile.
+    const u32 share = total_items / gridDim.x, extra = total_items % gridDim.x;
+    u32 item = blockIdx.x * share + min(blockIdx.x, extra);
+    const u32 item_end = item + share + (blockIdx.x < extra ? 1u : 0u);
+#pragma unroll 1
+    while (item < item_end) {
+    // (the quotient is wave-uniform but comes out of the VALU's float-reciprocal division sequence: readfirstlane moves it
+    // back to an SGPR so that everything derived from it — tile base, column pointers — stays scalar)
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(item / n_cols));   // tile index
+    const u32 col0 = item - hi * n_cols;
+    const u32 col1 = min(n_cols, col0 + (item_end - item));
+    item += col1 - col0;
     const size_t base = (size_t)hi << LOGT;
 
     // twiddles of this lane's 16-word run for layers 1..3 (registers, doubled); layer 0 reuses layer 1's
@@ -188,7 +197,11 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
             }
 #pragma unroll
             for (int j = 0; j < 4; j++)
+#ifdef TSTWO_EXP_B_STORE
+                *reinterpret_cast<uint4 *>(data + 4 * t + j * QT) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#else
                 *reinterpret_cast<uint4 *>(data + 16 * t + 4 * j) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+#endif
             lds_barrier();
         } else {
             u32 v[16];
@@ -230,6 +243,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
             lds_barrier();
         }
     }
+    }   // runs of one tile
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -238,11 +252,14 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
 // n - EXT in its own buffers (`src`), zero-extended to log size n on the fly.  The top EXT layers of a zero-padded input
 // only replicate (butterfly(a, 0, t) = (a, a)), so the quarter-tile vectors a lane needs are copies of each other:
 // they are loaded once from the small polynomial, the replicated layers are skipped, and the result goes to `cols`.
-template <bool INV, int K, int EXT = 0>
-__global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 cols_per_wg, u32 n, u32 lo,
+// LOGT (12..14) = log2 of the tile: 2^(LOGT-4) lanes.  14 is the default; the smaller tiles exist for transforms of few
+// columns, where 2^(n-14) tiles would leave most of the 256 CUs without a workgroup.
+template <bool INV, int K, int EXT = 0, int LOGT = 14>
+__global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_cols, u32 total_items, u32 n, u32 lo,
                                                 const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<EXT>::type src) {
     static_assert(EXT == 0 || (!INV && K >= 2 && EXT <= 2), "fused extension: forward pass with two register layers");
-    constexpr int LOGT = 14, THREADS = 1024, C = LOGT - K;
+    static_assert(LOGT >= 12 && LOGT <= 14 && LOGT - K >= 4, "strided tile: rows of at least 16 words");
+    constexpr int THREADS = 1 << (LOGT - 4), C = LOGT - K;
     constexpr u32 T = 1u << LOGT, QT = T / 4;
     constexpr int F = K >= 2 ? 2 : 1;          // layers fused into the load / store
     constexpr int R = K - F;                   // layers run as LDS stages
@@ -251,10 +268,16 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     u32 *twl = lds + T + T / 32;               // heap of 2^K entries (levels F..K-1)
     const u32 t = threadIdx.x;
-    const u32 groups = (n_cols + cols_per_wg - 1) / cols_per_wg;
-    const u32 tile = blockIdx.x / groups;
-    const u32 col0 = (blockIdx.x % groups) * cols_per_wg;
-    const u32 col1 = min(col0 + cols_per_wg, n_cols);
+    // contiguous range of (tile, column) work items, as in k_cfft_b
+    const u32 share = total_items / gridDim.x, extra = total_items % gridDim.x;
+    u32 item = blockIdx.x * share + min(blockIdx.x, extra);
+    const u32 item_end = item + share + (blockIdx.x < extra ? 1u : 0u);
+#pragma unroll 1
+    while (item < item_end) {
+    const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)(item / n_cols));
+    const u32 col0 = item - tile * n_cols;
+    const u32 col1 = min(n_cols, col0 + (item_end - item));
+    item += col1 - col0;
     const u32 mid_bits = lo - C;
     const u32 mid = tile & ((1u << mid_bits) - 1u);
     const u32 hi = tile >> mid_bits;
@@ -355,8 +378,14 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
 #pragma unroll
                     for (int m = 0; m < (1 << G2); m++) v[m] = lds[pad(e_final(tt, g, 0)) + off<C>(m)];
                     group_layers<G2, C, LOGT, false>(v, twl, high);
+#ifdef TSTWO_EXP_A_STORE
+#pragma unroll
+                    for (int m = 0; m < (1 << G2); m += 4)
+                        *reinterpret_cast<uint4 *>(data + goff(4 * t + ((g * (1 << G2) + m) / 4) * QT)) = make_uint4(v[m], v[m + 1], v[m + 2], v[m + 3]);
+#else
 #pragma unroll
                     for (int m = 0; m < (1 << G2); m++) data[goff(e_final(tt, g, m))] = v[m];
+#endif
                 }
                 lds_barrier();
             }
@@ -411,6 +440,7 @@ __global__ void __launch_bounds__(1024) k_cfft_a(ColPtrs cols, u32 n_cols, u32 c
             lds_barrier();
         }
     }
+    }   // runs of one tile
 }
 
 }  // namespace fast

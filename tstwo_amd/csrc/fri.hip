@@ -6,6 +6,7 @@
 // twiddle tree.  One lane per output row on SoA QM31 (4 coalesced 8-byte loads, 4 coalesced stores).
 // Algorithmic bytes per output row: fold_line 48 (32 in + 16 out), fold_circle_into_line 64
 // (32 src + 16 dst in + 16 dst out).
+#include <string.h>
 #include <vector>
 
 #include "common.h"
@@ -94,61 +95,116 @@ __global__ void __launch_bounds__(256) k_decompose_apply(CSoa4 in, Soa4 out, siz
 }
 
 // ---------------------------------------------------------------- eval_at_point
-// fold (poly/utils.ts:36-59) bottom-up: every lane folds 2^S consecutive inputs with the S innermost
-// remaining factors; factors are ordered innermost-first: [y, x, pi(x), pi^2(x), ...] (circle.ts:61-66).
-struct FoldFactors { qm31 f[5]; };
-template <bool FIRST>
-__global__ void __launch_bounds__(256) k_fold_chunk(const u32 *__restrict__ coeffs, const qm31 *__restrict__ partial_in,
-                                                   qm31 *__restrict__ partial_out, size_t n_out, int S, FoldFactors ff) {
-    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n_out) return;
-    qm31 v[32];
-    const int cnt = 1 << S;
+// PolyOps.eval_at_point (backend/cpu/circle.ts:52-69) = fold(coeffs, [y, x, pi(x), pi^2(x), ...] reversed)
+// (poly/utils.ts:36-59).  Unrolled, the fold is the multilinear form
+//     value = sum_i coeffs[i] * prod_{s : bit s of i is set} fac[s],      fac = [y, x, pi(x), pi^2(x), ...],
+// and the product splits over any partition of the index bits.  One pass over the coefficients (kernel E1), then one tiny
+// kernel per further 12 index bits (E2):
+//   E1  a workgroup of 256 lanes owns 4096 consecutive coefficients.  Lane t reads four 16-byte vectors, a KiB apart per
+//       wave (fully coalesced): coefficient (r, t, j) = base + 1024 r + 4 t + j.  Bits {0,1} (j) and {10,11} (r) are the same
+//       for every lane, so their 16 factor products W[r][j] arrive as kernel arguments (SGPRs) and the lane's 16 terms are
+//       16 x 4 v_mad_u64_u32 (M31 x QM31 = 4 multiplications, accumulated lazily in 64 bits).  Bits 2..9 (t) give a
+//       per-lane factor A[t & 15] * B[t >> 4] from two 16-entry tables that 32 lanes build in LDS while the loads are in
+//       flight.  After that the workgroup's partial is a plain sum over lanes (DPP-free shuffles + one LDS hop).
+//   E2  folds up to 4096 QM31 partials per workgroup the same way (QM31 x QM31 terms), bits 8..11 through a 16-entry
+//       argument table, bits 0..7 through the lane factor.
+// log 22: 1024 workgroups + one; the result is read back with one 16-byte copy.  Algorithmic bytes: 4 per coefficient.
+struct EvalW { qm31 w[16]; };        // products over the 4 "uniform" bits of a level (entry 0 = 1)
+struct EvalF { qm31 f[8]; };         // factors of the 8 lane bits of a level (A: f[0..3], B: f[4..7])
+
+__device__ __forceinline__ u32 red64(u64 x) {          // x < 2^64: canonical x mod P
+    u64 f = (x & M31_P) + (x >> 31);                     // < 2^31 + 2^33
+    return m31_reduce64(f);
+}
+// lane factor tables: entry e < 16 = prod_{i<4, bit i of e} f[i]; entry 16 + e = the same over f[4..7]
+__device__ __forceinline__ void eval_build_tables(qm31 *tab, const EvalF &ff) {
+    const u32 t = threadIdx.x;
+    if (t < 32) {
+        const u32 e = t & 15;
+        const int o = t < 16 ? 0 : 4;
+        qm31 v = {1u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        if (j < cnt) {
-            if (FIRST) v[j] = qm31_from_m31(coeffs[(o << S) + j]);
-            else v[j] = partial_in[(o << S) + j];
+        for (int i = 0; i < 4; i++) {
+            const qm31 f = (o == 0) ? ff.f[i] : ff.f[4 + i];
+            const qm31 p = qm31_mul(v, f);
+            if ((e >> i) & 1) v = p;
         }
+        tab[t] = v;
     }
+}
+// sum of one QM31 per lane over the workgroup (256 lanes); the result is valid in lane 0
+__device__ __forceinline__ qm31 eval_wg_sum(qm31 v, qm31 *scratch /* >= 4 entries */) {
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-        if (s < S) {
-#pragma unroll
-            for (int j = 0; j < (16 >> s); j++)
-                if (j < (cnt >> (s + 1))) v[j] = qm31_add(v[2 * j], qm31_mul(v[2 * j + 1], ff.f[s]));
-        }
+    for (int off = 32; off > 0; off >>= 1) {
+        qm31 o = {(u32)__shfl_down((int)v.a, off, 64), (u32)__shfl_down((int)v.b, off, 64), (u32)__shfl_down((int)v.c, off, 64),
+                  (u32)__shfl_down((int)v.d, off, 64)};
+        v = qm31_add(v, o);
     }
-    partial_out[o] = v[0];
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) v = qm31_add(qm31_add(scratch[0], scratch[1]), qm31_add(scratch[2], scratch[3]));
+    return v;
 }
 
-// Same fold for up to 64 columns of one size at one point: blockIdx.y = column; partial buffers are column-strided.
-template <bool FIRST>
-__global__ void __launch_bounds__(256) k_fold_chunk_batch(ColPtrs cols, const qm31 *__restrict__ partial_in, size_t in_stride,
-                                                         qm31 *__restrict__ partial_out, size_t out_stride, size_t n_out, int S, FoldFactors ff) {
-    size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n_out) return;
-    const u32 *__restrict__ coeffs = colp(cols, blockIdx.y);
-    partial_in += (size_t)blockIdx.y * in_stride;
-    partial_out += (size_t)blockIdx.y * out_stride;
-    qm31 v[32];
-    const int cnt = 1 << S;
+// E1: coefficients -> one partial per 4096-coefficient chunk.  grid = (chunks, columns).  n_coeffs < 4096 or unaligned
+// columns take the guarded scalar loads (coefficients beyond the polynomial count as zero).
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_eval_coeffs(ColPtrs cols, size_t n_coeffs, EvalW W, EvalF F, qm31 *__restrict__ partial_out,
+                                                    size_t out_stride) {
+    __shared__ qm31 tab[32 + 4];
+    const u32 t = threadIdx.x;
+    const u32 *__restrict__ c = colp(cols, blockIdx.y);
+    const size_t base = (size_t)blockIdx.x * 4096 + 4 * t;
+    uint4 x[4];
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        if (j < cnt) {
-            if (FIRST) v[j] = qm31_from_m31(coeffs[(o << S) + j]);
-            else v[j] = partial_in[(o << S) + j];
+    for (int r = 0; r < 4; r++) {
+        const size_t i = base + 1024 * (size_t)r;
+        if (FAST) {
+            x[r] = *reinterpret_cast<const uint4 *>(c + i);
+        } else {
+            x[r].x = i + 0 < n_coeffs ? c[i + 0] : 0u; x[r].y = i + 1 < n_coeffs ? c[i + 1] : 0u;
+            x[r].z = i + 2 < n_coeffs ? c[i + 2] : 0u; x[r].w = i + 3 < n_coeffs ? c[i + 3] : 0u;
         }
     }
+    eval_build_tables(tab, F);               // overlaps the loads above
+    __syncthreads();
+    const qm31 ft = qm31_mul(tab[t & 15], tab[16 + (t >> 4)]);
+    u32 ua = 0, ub = 0, uc = 0, ud = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-        if (s < S) {
+    for (int r = 0; r < 4; r++) {
+        const u32 v[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
+        u64 a = ua, b = ub, cc = uc, d = ud;     // 4 products < 2^62 each + carry-in < 2^31: no overflow
 #pragma unroll
-            for (int j = 0; j < (16 >> s); j++)
-                if (j < (cnt >> (s + 1))) v[j] = qm31_add(v[2 * j], qm31_mul(v[2 * j + 1], ff.f[s]));
+        for (int j = 0; j < 4; j++) {
+            const qm31 w = W.w[4 * r + j];
+            a += (u64)v[j] * w.a; b += (u64)v[j] * w.b; cc += (u64)v[j] * w.c; d += (u64)v[j] * w.d;
         }
+        ua = red64(a); ub = red64(b); uc = red64(cc); ud = red64(d);
     }
-    partial_out[o] = v[0];
+    qm31 v = qm31_mul(qm31{ua, ub, uc, ud}, ft);
+    v = eval_wg_sum(v, tab + 32);
+    if (t == 0) partial_out[(size_t)blockIdx.y * out_stride + blockIdx.x] = v;
+}
+
+// E2: QM31 partials -> one partial per 4096 of them (R = 16 per lane; fewer when m_in < 4096).  grid = (groups, columns).
+__global__ void __launch_bounds__(256) k_eval_partials(const qm31 *__restrict__ partial_in, size_t in_stride, size_t m_in, EvalW W, EvalF F,
+                                                      qm31 *__restrict__ partial_out, size_t out_stride) {
+    __shared__ qm31 tab[32 + 4];
+    const u32 t = threadIdx.x;
+    const qm31 *__restrict__ in = partial_in + (size_t)blockIdx.y * in_stride + (size_t)blockIdx.x * 4096;
+    const size_t left = m_in - (size_t)blockIdx.x * 4096;      // entries of this group (>= 1)
+    eval_build_tables(tab, F);
+    __syncthreads();
+    const qm31 ft = qm31_mul(tab[t & 15], tab[16 + (t >> 4)]);
+    qm31 acc = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+    for (int r = 0; r < 16; r++) {
+        const size_t i = (size_t)r * 256 + t;
+        if (i < left) acc = qm31_add(acc, qm31_mul(in[i], W.w[r]));
+    }
+    qm31 v = qm31_mul(acc, ft);
+    v = eval_wg_sum(v, tab + 32);
+    if (t == 0) partial_out[(size_t)blockIdx.y * out_stride + blockIdx.x] = v;
 }
 
 unsigned capped_blocks(size_t work_items, unsigned threads) {
@@ -338,55 +394,100 @@ int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32
     return TSTWO_OK;
 }
 
+// eval_at_point of n_cols polynomials of one size at one point: kernels E1/E2 above, one read-back of 16 bytes per column.
+static int eval_at_point_impl(const u32 *const *coeffs, size_t n_cols, u32 log_size, const u32 px[4], const u32 py[4], u32 *out) {
+    Context &c = ctx();
+    if (log_size == 0) {   // circle.ts:53-59: the constant polynomial
+        for (size_t i = 0; i < n_cols; i++) {
+            u32 v;
+            { int rc2 = small_d2h(&v, coeffs[i], 4); if (rc2) return rc2; }
+            out[4 * i] = v; out[4 * i + 1] = out[4 * i + 2] = out[4 * i + 3] = 0;
+        }
+        return TSTWO_OK;
+    }
+    // fac[s] multiplies every coefficient whose index has bit s set: y, x, pi(x), ... (circle.ts:61-67 before the reverse)
+    const host::Q one = {{1, 0, 0, 0}}, zero = {{0, 0, 0, 0}};
+    host::Q fac[44];
+    fac[0] = to_hq(py);
+    {
+        host::Q x = to_hq(px);
+        for (u32 i = 1; i < log_size; i++) {
+            fac[i] = x;
+            host::Q sx = host::qmul(x, x);
+            x = host::qsub(host::qadd(sx, sx), one);   // circle.ts:37-40
+        }
+        for (u32 i = log_size; i < 44; i++) fac[i] = zero;   // bits the polynomial does not have: those coefficients are zero
+    }
+    auto level_tables = [&](const int (&wbits)[4], u32 lane_bit0, EvalW &W, EvalF &F) {
+        for (int e = 0; e < 16; e++) {
+            host::Q v = one;
+            for (int i = 0; i < 4; i++)
+                if ((e >> i) & 1) v = host::qmul(v, fac[wbits[i]]);
+            W.w[e] = to_q(v);
+        }
+        for (int i = 0; i < 8; i++) F.f[i] = to_q(fac[lane_bit0 + i]);
+    };
+    const size_t n_coeffs = (size_t)1 << log_size;
+    const size_t chunks = log_size > 12 ? (size_t)1 << (log_size - 12) : 1;
+    const size_t groups1 = chunks > 4096 ? chunks / 4096 : 1;
+    bool aligned = true;
+    for (size_t i = 0; i < n_cols; i++) aligned = aligned && ((((uintptr_t)coeffs[i]) & 15) == 0);
+    const bool fast = log_size >= 12 && aligned;
+    const size_t kChunkCols = 32768;                       // gridDim.y limit
+    for (size_t col0 = 0; col0 < n_cols; col0 += kChunkCols) {
+        const size_t g = n_cols - col0 < kChunkCols ? n_cols - col0 : kChunkCols;
+        int rc = ensure_scratch((g * (chunks + groups1) + 8) * sizeof(qm31));
+        if (rc) return rc;
+        qm31 *bufA = (qm31 *)c.scratch, *bufB = bufA + g * chunks;
+        // the last level stores its g results straight into the page-locked host buffer (device-visible): the call then ends
+        // with one stream synchronisation instead of a copy + synchronisation
+        qm31 *host_dst = (c.pinned && g * sizeof(qm31) <= kPinnedBytes) ? (qm31 *)c.pinned : nullptr;
+        ColPtrs cp;
+        rc = fill_col_table(cp, coeffs + col0, g, 0);
+        if (rc) return rc;
+        EvalW W;
+        EvalF F;
+        {   // E1: bits 0,1 (j) and 10,11 (r) through W[4 r + j]; bits 2..9 are the lane bits
+            const int wb[4] = {0, 1, 10, 11};
+            level_tables(wb, 2, W, F);
+            const size_t stride = chunks == 1 ? 1 : chunks;
+            qm31 *o = (chunks == 1 && host_dst) ? host_dst : bufA;
+            if (fast)
+                hipLaunchKernelGGL(k_eval_coeffs<true>, dim3((unsigned)chunks, (unsigned)g), dim3(256), 0, c.stream, cp, n_coeffs, W, F, o, stride);
+            else
+                hipLaunchKernelGGL(k_eval_coeffs<false>, dim3((unsigned)chunks, (unsigned)g), dim3(256), 0, c.stream, cp, n_coeffs, W, F, o, stride);
+        }
+        qm31 *src = bufA, *dst = bufB;
+        size_t m_in = chunks;
+        u32 bit0 = 12;
+        while (m_in > 1) {   // E2: 12 more bits per level (lane bits bit0..bit0+7, W over bit0+8..bit0+11)
+            const int wb[4] = {(int)bit0 + 8, (int)bit0 + 9, (int)bit0 + 10, (int)bit0 + 11};
+            level_tables(wb, bit0, W, F);
+            const size_t groups = m_in > 4096 ? m_in / 4096 : 1;
+            hipLaunchKernelGGL(k_eval_partials, dim3((unsigned)groups, (unsigned)g), dim3(256), 0, c.stream, (const qm31 *)src, m_in, m_in, W, F,
+                               (groups == 1 && host_dst) ? host_dst : dst, groups);
+            qm31 *tmp = src; src = dst; dst = tmp;
+            m_in = groups;
+            bit0 += 12;
+        }
+        TSTWO_LAUNCH_CHECK();
+        // one QM31 per column, contiguous (the last level has stride 1)
+        if (host_dst) {
+            TSTWO_HIP(hipStreamSynchronize(c.stream));
+            memcpy(out + 4 * col0, host_dst, g * sizeof(qm31));
+        } else {
+            rc = small_d2h(out + 4 * col0, src, g * sizeof(qm31));
+            if (rc) return rc;
+        }
+    }
+    return TSTWO_OK;
+}
+
 int tstwo_eval_at_point(const u32 *coeffs, u32 log_size, const u32 px[4], const u32 py[4], u32 out[4]) {
     TSTWO_REQUIRE_READY();
     TSTWO_REQUIRE_PTRS(coeffs, px, py, out);
     if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: log size out of range");
-    Context &c = ctx();
-    if (log_size == 0) {   // circle.ts:53-59
-        u32 v;
-        { int rc2 = small_d2h(&v, coeffs, 4); if (rc2) return rc2; }
-        out[0] = v; out[1] = out[2] = out[3] = 0;
-        return TSTWO_OK;
-    }
-    // innermost-first factors: y, x, pi(x), ... (circle.ts:61-67 before the reverse)
-    host::Q fac[32];
-    fac[0] = to_hq(py);
-    host::Q x = to_hq(px), one;
-    one.v[0] = 1; one.v[1] = one.v[2] = one.v[3] = 0;
-    for (u32 i = 1; i < log_size; i++) {
-        fac[i] = x;
-        host::Q sx = host::qmul(x, x);
-        x = host::qsub(host::qadd(sx, sx), one);   // circle.ts:37-40
-    }
-    size_t n1 = (size_t)1 << (log_size > 5 ? log_size - 5 : 0);
-    int rc = ensure_scratch(2 * (n1 + 64) * sizeof(qm31));
-    if (rc) return rc;
-    qm31 *bufA = (qm31 *)c.scratch, *bufB = bufA + n1 + 32;
-    u32 done = 0;
-    size_t cur = (size_t)1 << log_size;
-    bool first = true;
-    qm31 *src = nullptr, *dst = bufA;
-    while (done < log_size) {
-        int S = (int)(log_size - done < 5 ? log_size - done : 5);
-        size_t n_out = cur >> S;
-        FoldFactors ff;
-        for (int s = 0; s < 5; s++) ff.f[s] = s < S ? to_q(fac[done + s]) : qm31{0, 0, 0, 0};
-        if (first)
-            hipLaunchKernelGGL(k_fold_chunk<true>, dim3(ceil_div(n_out, 256)), dim3(256), 0, c.stream, coeffs, (const qm31 *)nullptr, dst, n_out, S, ff);
-        else
-            hipLaunchKernelGGL(k_fold_chunk<false>, dim3(ceil_div(n_out, 256)), dim3(256), 0, c.stream, (const u32 *)nullptr, (const qm31 *)src, dst, n_out, S, ff);
-        first = false;
-        done += (u32)S;
-        cur = n_out;
-        src = dst;
-        dst = (dst == bufA) ? bufB : bufA;
-    }
-    TSTWO_LAUNCH_CHECK();
-    qm31 r;
-    { int rc2 = small_d2h(&r, src, sizeof(r)); if (rc2) return rc2; }
-    out[0] = r.a; out[1] = r.b; out[2] = r.c; out[3] = r.d;
-    return TSTWO_OK;
+    return eval_at_point_impl(&coeffs, 1, log_size, px, py, out);
 }
 
 // eval_at_point of n_cols polynomials of one size at one point (CommitmentSchemeProver.prove_values samples every
@@ -398,63 +499,7 @@ int tstwo_eval_at_point_batch(const u32 *const *coeffs, size_t n_cols, u32 log_s
     if (!coeffs || !out) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: null argument");
     TSTWO_REQUIRE_TABLE(coeffs, n_cols); TSTWO_REQUIRE_PTRS(px, py);
     if (log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "eval_at_point: log size out of range");
-    if (log_size == 0 || n_cols == 1) {
-        for (size_t i = 0; i < n_cols; i++) {
-            int rc = tstwo_eval_at_point(coeffs[i], log_size, px, py, out + 4 * i);
-            if (rc) return rc;
-        }
-        return TSTWO_OK;
-    }
-    Context &c = ctx();
-    host::Q fac[32];
-    fac[0] = to_hq(py);
-    host::Q x = to_hq(px), one;
-    one.v[0] = 1; one.v[1] = one.v[2] = one.v[3] = 0;
-    for (u32 i = 1; i < log_size; i++) {
-        fac[i] = x;
-        host::Q sx = host::qmul(x, x);
-        x = host::qsub(host::qadd(sx, sx), one);
-    }
-    const size_t n1 = (size_t)1 << (log_size > 5 ? log_size - 5 : 0);
-    const size_t stride = n1 + 32;
-    for (size_t base = 0; base < n_cols; base += 64) {
-        const size_t g = n_cols - base < 64 ? n_cols - base : 64;
-        int rc = ensure_scratch(2 * g * stride * sizeof(qm31));
-        if (rc) return rc;
-        ColPtrs cp;
-        cp.ext = nullptr;
-        for (size_t i = 0; i < 64; i++) cp.p[i] = const_cast<u32 *>(coeffs[base + (i < g ? i : 0)]);
-        qm31 *bufA = (qm31 *)c.scratch, *bufB = bufA + g * stride;
-        u32 done = 0;
-        size_t cur = (size_t)1 << log_size;
-        bool first = true;
-        qm31 *src = nullptr, *dst = bufA;
-        while (done < log_size) {
-            int S = (int)(log_size - done < 5 ? log_size - done : 5);
-            size_t n_out = cur >> S;
-            FoldFactors ff;
-            for (int s = 0; s < 5; s++) ff.f[s] = s < S ? to_q(fac[done + s]) : qm31{0, 0, 0, 0};
-            dim3 grid(ceil_div(n_out, 256), (unsigned)g);
-            if (first)
-                hipLaunchKernelGGL(k_fold_chunk_batch<true>, grid, dim3(256), 0, c.stream, cp, (const qm31 *)bufA, stride, dst, stride, n_out, S, ff);
-            else
-                hipLaunchKernelGGL(k_fold_chunk_batch<false>, grid, dim3(256), 0, c.stream, cp, (const qm31 *)src, stride, dst, stride, n_out, S, ff);
-            first = false;
-            done += (u32)S;
-            cur = n_out;
-            src = dst;
-            dst = (dst == bufA) ? bufB : bufA;
-        }
-        TSTWO_LAUNCH_CHECK();
-        std::vector<qm31> r(g);
-        TSTWO_HIP(hipMemcpy2DAsync(r.data(), sizeof(qm31), src, stride * sizeof(qm31), sizeof(qm31), g, hipMemcpyDeviceToHost, c.stream));
-        TSTWO_HIP(hipStreamSynchronize(c.stream));
-        for (size_t i = 0; i < g; i++) {
-            u32 *o = out + 4 * (base + i);
-            o[0] = r[i].a; o[1] = r[i].b; o[2] = r[i].c; o[3] = r[i].d;
-        }
-    }
-    return TSTWO_OK;
+    return eval_at_point_impl(coeffs, n_cols, log_size, px, py, out);
 }
 
 }  // extern "C"

@@ -8,6 +8,42 @@ import numpy as np
 from .backend import shard_columns  # re-export
 
 
+class HipComm:
+    """The library's own RCCL communicator (include/tstwo_hip.h "multi-GPU"): what a Bun host binds.  One per process.
+
+    `exchange_id(id_or_None) -> id`: any host-side broadcast of 128 bytes from rank 0 (a file, a socket, torch.distributed
+    on gloo, an environment variable set by the launcher)."""
+
+    def __init__(self, rank: int, world: int, exchange_id):
+        import ctypes as C
+        from . import _lib as L
+        L.ensure_init()
+        mine = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            L.call("tstwo_comm_unique_id", buf)
+            mine = bytes(buf)
+        uid = exchange_id(mine)
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        L.call("tstwo_comm_init", rank, world, (C.c_uint8 * 128).from_buffer_copy(bytes(uid)))
+        self.rank, self.world = rank, world
+
+    def allgather_roots(self, layers_or_root_ptr: int) -> list:
+        """All-gather of the 32 bytes at a device address (byte 0 of a tstwo_merkle_commit layers buffer = the root):
+        returns the world's roots in rank order, as bytes."""
+        import ctypes as C
+        from . import _lib as L
+        out = L.DeviceBuffer(32 * self.world)
+        L.call("tstwo_allgather_roots", C.c_void_p(layers_or_root_ptr), C.c_void_p(out.ptr))
+        flat = out.download(np.uint8, 32 * self.world).tobytes()
+        return [flat[32 * r:32 * r + 32] for r in range(self.world)]
+
+    def close(self):
+        from . import _lib as L
+        L.call("tstwo_comm_destroy")
+
+
 def allgather_roots(root: bytes, group=None, device=None) -> list:
     """Every rank contributes its 32-byte root; returns the world's roots in rank order (stwo's TreeVec order,
     pcs/prover.ts:62-64,227-228 comment: each root is then mixed into the channel in order)."""
