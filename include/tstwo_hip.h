@@ -132,7 +132,8 @@ int tstwo_twiddles_build(uint32_t coset_initial, uint32_t log_size, uint32_t *tw
  * "twiddle tree mismatch").  evaluate expects coefficients already extended to 2^log_size
  * (tstwo_poly_extend).  The true transform (Rust-exact) is computed; the reference's log_size==3
  * output swap (circle.ts:123-131) is offered by the wrapper as a compat option, not here.
- * 1 <= log_size <= 28 (a 1 GiB column); larger sizes return TSTWO_ERR_BAD_ARG. */
+ * 1 <= log_size <= 30 = MAX_CIRCLE_DOMAIN_LOG_SIZE (poly/circle/domain.ts:4; a 4 GiB column); larger sizes return
+ * TSTWO_ERR_BAD_ARG. */
 int tstwo_cfft_evaluate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,
                         const uint32_t *tw, uint32_t tw_log);
 int tstwo_cfft_interpolate(uint32_t *const *cols, size_t n_cols, uint32_t log_size, uint32_t half_initial,

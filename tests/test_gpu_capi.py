@@ -540,10 +540,11 @@ def test_cfft_interpolate_to_matches_in_place(n):
     assert (dst[0].download() == evals[0]).all()
 
 
-@pytest.mark.parametrize("n", [25, 26, 27, 28])
+@pytest.mark.parametrize("n", [25, 26, 27, 28, 29, 30])
 def test_cfft_maximum_sizes(n):
-    """The largest transforms the tiled path plans (3 passes at log 26, 3 at log 28; 1 GiB column at log 28): the
-    evaluation agrees with eval_at_point at sampled domain points and interpolate inverts it."""
+    """The largest transforms the tiled path plans, up to the reference's MAX_CIRCLE_DOMAIN_LOG_SIZE = 30
+    (poly/circle/domain.ts:4; 3 passes from log 23, a 4 GiB column at log 30): the evaluation agrees with eval_at_point at
+    sampled domain points, interpolate inverts it, and (log 29, 30) the transform is linear."""
     tw, itw = build_twiddles(n - 1)
     a = rand_column(n, 1 << n)
     d = [dev(a)]
@@ -561,15 +562,24 @@ def test_cfft_maximum_sizes(n):
         p = OL.orc_circle_domain_at(half_odds(n - 1), n - 1, i)
         v = orc.eval_at_point(a, n, (p.x, 0, 0, 0), (p.y, 0, 0, 0))
         assert v == (int(d[0].download(np.uint32, 1, 4 * OL.orc_bit_reverse_index(i, n))[0]), 0, 0, 0)
+    if n >= 29:      # linearity: evaluate(b) + evaluate(a) == evaluate(a + b), all three on the device
+        b = dev(rand_column(n + 100, 1 << n))
+        s_ = dev_empty(1 << n)
+        L.call("tstwo_m31_add", vp(coeffs), vp(b), vp(s_), 1 << n)
+        L.call("tstwo_cfft_evaluate", ptrs([b, s_]), 2, n, half_odds(n - 1), vp(tw), n - 1)
+        L.call("tstwo_m31_add", vp(d[0]), vp(b), vp(b), 1 << n)
+        assert (host(b, 1 << n) == host(s_, 1 << n)).all()
+        b.free()
+        s_.free()
     L.call("tstwo_cfft_interpolate", ptrs(d), 1, n, half_odds(n - 1), vp(itw), n - 1)
     back = host(d[0], 1 << n)
     assert (back == a).all()
 
 
-def test_cfft_rejects_sizes_above_28():
+def test_cfft_rejects_sizes_above_30():
     d = dev(rand_column(1, 16))
-    with pytest.raises(L.TstwoError, match="log_size > 28 is not supported"):
-        L.call("tstwo_cfft_evaluate", ptrs([d]), 1, 29, 1, vp(d), 28)
+    with pytest.raises(L.TstwoError, match="exceeds MAX_CIRCLE_DOMAIN_LOG_SIZE"):
+        L.call("tstwo_cfft_evaluate", ptrs([d]), 1, 31, 1, vp(d), 30)
 
 
 def test_null_pointers_are_errors_not_faults():

@@ -34,6 +34,7 @@ namespace {
 
 constexpr u32 kMaxLogTileB = 13;   // contiguous (bottom) tile: 2^13 words = 32 KiB + pad, 256 lanes
 constexpr u32 kLogTileA = 14;      // strided tile: 2^k rows x 2^(14-k) words = 64 KiB + pad, 512 lanes
+constexpr u32 kMaxLogSize = 30;    // MAX_CIRCLE_DOMAIN_LOG_SIZE (poly/circle/domain.ts:4): a 4 GiB column; word offsets stay below 2^30
 constexpr u32 kMaxKA = 9;          // at most 9 layers per strided pass (rows of >= 32 words = 128 B)
 constexpr int kThreadsB = 256, kThreadsA = 512;
 constexpr int kMaxV4 = 8;          // 16-byte vectors per lane per tile (32 words)
@@ -512,7 +513,7 @@ template <bool INV>
 int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw, u32 tw_log) {
     TSTWO_REQUIRE_READY();
     if (n == 0 || n > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
-    if (n > 28) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size > 28 is not supported (1 GiB per column is the largest tested transform)");
+    if (n > kMaxLogSize) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size > 30 exceeds MAX_CIRCLE_DOMAIN_LOG_SIZE (poly/circle/domain.ts:4)");
     if (n_cols == 0) return TSTWO_OK;
     if (!cols) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
     Context &c = ctx();
@@ -572,7 +573,7 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
     if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
     const u32 *tw_end = tw + ((size_t)1 << tw_log);
-    const bool fast_path = n >= kMaxLogTileB && n <= 28;
+    const bool fast_path = n >= kMaxLogTileB && n <= kMaxLogSize;
     const char *dbg_env = getenv("TSTWO_CFFT_GENERIC");      // debugging aid: 1 = generic kernel for the bottom pass, 2 = for strided passes
     const int dbg_generic = dbg_env ? atoi(dbg_env) : 0;      // specialised kernels (cfft_fast.cuh); smaller sizes use the generic one
     // All columns go through a pass in one launch.  (Measured on MI355X, 32 x 2^22: running the passes back to back
@@ -626,7 +627,7 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
     if (!src || !dst) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
     TSTWO_REQUIRE_TABLE(src, n_cols); TSTWO_REQUIRE_TABLE(dst, n_cols);
     if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
-    const bool tiled = log_size >= kMaxLogTileB && log_size <= 28 && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
+    const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
                        !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_OOP");
     if (tiled) {
         if (!itw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
@@ -687,7 +688,7 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
     const u32 ext = log_size - log_poly;
     Pass passes[8];
     int np = 0;
-    const bool tiled = log_size >= kMaxLogTileB && log_size <= 28 && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
+    const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
                        !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_FUSED_EXTEND");
     if (tiled) np = plan_passes(log_size, passes);
     if (tiled && np >= 2 && (ext == 1 || ext == 2) && passes[np - 1].k >= 2) {

@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
     const u32 mid = tile & ((1u << mid_bits) - 1u);
     const u32 hi = tile >> mid_bits;
     const size_t base = ((size_t)hi << (lo + K)) | ((size_t)mid << C);
-    // tile-relative word offset (fits 32 bits: the launcher only uses this kernel for lo + K <= 28)
+    // tile-relative word offset: < 2^(lo + K) <= 2^30 words (log_size <= 30), so 32 bits hold it
     auto goff = [&](u32 e) -> u32 { return ((e >> C) << lo) + (e & ((1u << C) - 1u)); };
 
     if constexpr (R > 0) {
