@@ -274,7 +274,12 @@ def main():
         if args.pmc_json and os.path.exists(args.pmc_json):
             pj = json.load(open(args.pmc_json))
             traffic = pj.get("hbm_bytes_per_launch")
-            traffic_source = {"file": os.path.relpath(args.pmc_json, ROOT), "kernels": pj.get("kernels"), "lib_sha16": pj.get("lib_sha16")}
+            import hashlib
+            lib_now = hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
+            traffic_source = {"file": os.path.relpath(os.path.abspath(args.pmc_json), ROOT), "kernels": pj.get("cfft_kernels"),
+                              "lib_sha16": pj.get("lib_sha16"), "same_build": pj.get("lib_sha16") == lib_now}
+            if not traffic_source["same_build"]:
+                traffic = None          # counters of another build say nothing about this one
         out = {
             "metric": "M31 CFFT elems/sec at log_size=22 (per step: CFFT evaluate + Blake2s Merkle commit + root all-gather)",
             "value": total_elems / elapsed,

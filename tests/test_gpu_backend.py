@@ -496,6 +496,34 @@ def test_fri_prove_verify_single_column():
     _fri_verify(cfg, proof, [8], _query_evals([col], positions), positions)
 
 
+def test_fri_prove_verify_ts_compatible_transcript():
+    """tstwo_amd.set_semantics("ts"): the channel keeps the TS port's draw_felt queue (channel/blake2.ts:177-184).  Prover
+    (GPU folds and trees, host transcript: the device channel implements Rust's draw only, and says so) and verifier must
+    agree with each other, and disagree with the Rust-mode transcript of the same column."""
+    import warnings
+    cfg = T.FriConfig(2, 2, 12)
+    col, tw = _secure_low_degree_eval(8, 2, 6100)
+    _, rust_proof, rust_positions = _fri_prove([col], tw, cfg)
+    T.set_semantics("ts")
+    try:
+        assert T.Blake2sChannel().ts_compat and T.get_semantics() == "ts"
+        ch = T.Blake2sChannel()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            prover = T.FriProver.commit(ch, cfg, [col], tw)
+        assert any("ts-compatible channel" in str(x.message) for x in w)
+        proof, positions = prover.decommit(ch)
+        _fri_verify(cfg, proof, [8], _query_evals([col], positions), positions)     # _fri_verify builds its channel under "ts" too
+        assert positions != rust_positions or proof.last_layer_poly.coeffs != rust_proof.last_layer_poly.coeffs
+        # a Rust-mode verifier draws other challenges from the same proof: it must not accept it
+        with pytest.raises(Exception):
+            v = T.FriVerifier.commit(T.Blake2sChannel(ts_compat=False), cfg, proof, [T.CirclePolyDegreeBound(8)])
+            v.decommit(_query_evals([col], v.sample_query_positions(T.Blake2sChannel(ts_compat=False))))
+    finally:
+        T.set_semantics("rust")
+    assert not T.Blake2sChannel().ts_compat
+
+
 def test_fri_prove_verify_mixed_degree_columns():
     """Rust fri.rs valid_mixed_degree_proof_passes_verification: columns of log degree 9, 7, 5 under one first-layer tree."""
     cfg = T.FriConfig(1, 2, 10)

@@ -37,10 +37,17 @@ def main():
     k16 = cal.get("fetch_16B") or 2.0
     for k, d in res["kernels"].items():
         d["hbm_bytes_corrected"] = d["FETCH_SIZE_bytes_raw"] * k16 + d["WRITE_SIZE_bytes_raw"] * (cal.get("write_16B") or 1.0)
-    cf = [d for k, d in res["kernels"].items() if "k_cfft" in k]
+    cf = {k: d for k, d in res["kernels"].items() if "k_cfft" in k}
     if cf:
-        res["hbm_bytes_per_launch"] = sum(d["hbm_bytes_corrected"] for d in cf) / len(cf)   # avg over the transform's passes
+        res["hbm_bytes_per_launch"] = sum(d["hbm_bytes_corrected"] for d in cf.values()) / len(cf)   # avg over the transform's passes
         res["algorithmic_bytes_per_launch"] = 8.0 * (1 << 22) * 32 / len(cf)
+        res["cfft_kernels"] = sorted(cf)
+    # which build these counters belong to (bench.py --pmc-json copies this next to roofline.traffic)
+    import hashlib
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tstwo_amd", "libtstwo_hip.so")
+    if os.path.exists(lib):
+        res["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     print(json.dumps(res, indent=1))
 
 

@@ -33,5 +33,11 @@ layers = L.DeviceBuffer(32 * ((2 << n) - 1))
 for _ in range(2):
     L.call("tstwo_cfft_evaluate", ptrs, cols, n, half, vp(tw.ptr), n - 1)
     L.call("tstwo_merkle_commit", ptrs, L.u32x([n] * cols), cols, vp(layers.ptr), None)
+# PolyOps.eval_at_point: one column log 24 (64 MiB read once) + 32 columns log 20 at one point
+from tstwo_amd.circle import SECURE_FIELD_CIRCLE_GEN as G  # noqa: E402
+px, py, o4 = L.u32x(G.x.tup()), L.u32x(G.y.tup()), L.u32x([0] * 4)
+big = L.DeviceBuffer(4 << 24)
+big.upload(rng.integers(0, L.P, size=1 << 24, dtype=np.uint32))
+L.call("tstwo_eval_at_point", vp(big.ptr), 24, px, py, o4)
 L.sync()
 print("done")

@@ -1,33 +1,41 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh TAG'): regenerates every artefact profiles/ holds.
 # Output goes to gpurun_out/$TAG/ (scratch); tools/collect_profiles.sh copies the summaries into profiles/.
-set -eo pipefail
-TAG=${1:-r01}
+# Every profiled command sits behind `timeout -k`, and a progress line is printed after each stage.
+set -o pipefail
+TAG=${1:-r02}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-python3 bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
-echo "bench done"; tail -c 400 $O/bench.json
-python3 tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err
-echo "configs done"
-python3 tools/bench_callers.py > $O/callers.jsonl 2> $O/callers.err
-echo "callers done"
+T="timeout -k 10"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu > $O/stats.log 2>&1
-echo "stats done"
-rocprofv3 --kernel-trace --output-format csv -d $O/stats_configs -o configs -- python3 $R/tools/bench_configs.py > $O/stats_configs.log 2>&1
-echo "stats configs done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/pmc_target.py > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/pmc_target.py > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES --output-format csv -d $O/pmc_sq1 -o s1 -- python3 $R/tools/pmc_target.py > $O/pmc_sq1.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq2 -o s2 -- python3 $R/tools/pmc_target.py > $O/pmc_sq2.log 2>&1
-echo "pmc done"
+# 1. PMC passes (separate runs, --pmc only): HBM traffic with the guide's gfx950 corrections, then SQ counters
+$T 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/pmc_target.py > $O/pmc_fetch.log 2>&1
+$T 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/pmc_target.py > $O/pmc_write.log 2>&1
+echo "pmc traffic done"
+$T 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES --output-format csv -d $O/pmc_sq1 -o s1 -- python3 $R/tools/pmc_target.py > $O/pmc_sq1.log 2>&1
+$T 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq2 -o s2 -- python3 $R/tools/pmc_target.py > $O/pmc_sq2.log 2>&1
+echo "pmc sq done"
 cd $R
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/cfft_pmc.json
 python3 tools/sq_summary.py $O/pmc_sq1 $O/pmc_sq2 > $O/sq_counters.json
+# 2. the bench line (configs 1-4 inside), with the traffic of THIS build
+$T 500 python3 bench.py --steps 20 --warmup 3 --pmc-json $O/cfft_pmc.json > $O/bench.json 2> $O/bench.err
+echo "bench done"; tail -c 300 $O/bench.json
+# 3. kernel trace + stats of the same command (without the CPU leg and the config sweep) and of the config sweep
+cd /tmp
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-configs > $O/stats.log 2>&1
+echo "stats done"
+$T 300 rocprofv3 --kernel-trace --output-format csv -d $O/stats_configs -o configs -- python3 $R/tools/bench_configs.py --no-cpu > $O/stats_configs.log 2>&1
+echo "stats configs done"
+cd $R
 python3 tools/prof_summary.py $O/stats > $O/bench_kernel_summary.txt
 python3 tools/prof_summary.py $O/stats_configs > $O/configs_kernel_summary.txt
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+$T 300 python3 tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err
+echo "configs done"
+$T 300 python3 tools/bench_callers.py > $O/callers.jsonl 2> $O/callers.err
+echo "callers done"
 rm -rf $O/stats $O/stats_configs $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces are large; summaries are what is kept
 ls -la $O

@@ -5,6 +5,9 @@
 import { M31 } from "../../fields/m31";
 import { QM31 } from "../../fields/qm31";
 import type { Backend, Column } from "../index";
+import type { MerkleOps } from "../../vcs/ops";
+import { Blake2sHash } from "../../vcs/blake2_hash";
+import { quotientConstants, type ColumnSampleBatch } from "../cpu/quotients";
 import { CirclePoint, Coset } from "../../circle";
 import type { CircleDomain } from "../../poly/circle/domain";
 import { CirclePoly } from "../../poly/circle/poly";
@@ -31,6 +34,12 @@ export class HipColumn implements Column<M31> {
     return new HipColumn(b, len);
   }
   static uninitialized(len: number): HipColumn { return new HipColumn(new DeviceBuffer(4 * len), len); }
+  // Column<T> declares zeros / uninitialized as INSTANCE methods (backend/index.ts:54-58); CpuColumn throws in them, here they work
+  zeros(len: number): HipColumn { return HipColumn.zeros(len); }
+  uninitialized(len: number): HipColumn { return HipColumn.uninitialized(len); }
+  /** Array-style length, so that code written against `readonly BaseField[]` columns (MerkleProver.commit sorts and filters
+   *  by `c.length`, vcs/prover.ts:20-25) can be handed device columns. */
+  get length(): number { return this.n; }
   get dev(): bigint { return this.buf.dev; }
   clone(): HipColumn {
     const out = HipColumn.uninitialized(this.n);
@@ -48,22 +57,30 @@ export class HipColumn implements Column<M31> {
   set(i: number, v: M31): void { this.checkIndex(i); this.buf.upload(Uint32Array.of(v.value), 4 * i); }
 }
 
-/** SecureColumnByCoords on the device: 4 coordinate columns (fields/secure_columns.ts:124). */
-export class HipSecureColumn {
-  constructor(readonly columns: [HipColumn, HipColumn, HipColumn, HipColumn]) {}
+/** SecureColumnByCoords on the device: 4 coordinate columns (fields/secure_columns.ts:124); a Column<QM31> (backend/index.ts:53-74). */
+export class HipSecureColumn implements Column<QM31> {
+  constructor(readonly columns: [HipColumn, HipColumn, HipColumn, HipColumn]) {
+    if (!columns.every((c) => c.len() === columns[0].len())) throw new Error("coordinate column length mismatch");
+  }
   static from(values: readonly QM31[]): HipSecureColumn {
     const cols = [0, 1, 2, 3].map((k) => HipColumn.fromArray(values.map((q) => q.to_m31_array()[k]!)));
     return new HipSecureColumn(cols as [HipColumn, HipColumn, HipColumn, HipColumn]);
   }
-  static zeros(n: number): HipSecureColumn { return new HipSecureColumn([0, 1, 2, 3].map(() => HipColumn.zeros(n)) as any); }
-  static uninitialized(n: number): HipSecureColumn { return new HipSecureColumn([0, 1, 2, 3].map(() => HipColumn.uninitialized(n)) as any); }
+  static zeros(n: number): HipSecureColumn { return new HipSecureColumn([0, 1, 2, 3].map(() => HipColumn.zeros(n)) as [HipColumn, HipColumn, HipColumn, HipColumn]); }
+  static uninitialized(n: number): HipSecureColumn { return new HipSecureColumn([0, 1, 2, 3].map(() => HipColumn.uninitialized(n)) as [HipColumn, HipColumn, HipColumn, HipColumn]); }
+  zeros(len: number): HipSecureColumn { return HipSecureColumn.zeros(len); }
+  uninitialized(len: number): HipSecureColumn { return HipSecureColumn.uninitialized(len); }
   len(): number { return this.columns[0].len(); }
+  isEmpty(): boolean { return this.len() === 0; }
+  is_empty(): boolean { return this.isEmpty(); }                       // SecureColumnByCoords spelling (secure_columns.ts:154)
   ptrs(): BigUint64Array { return ptrs(this.columns.map((c) => c.dev)); }
   at(i: number): QM31 { return QM31.from_m31_array(this.columns.map((c) => c.at(i)) as [M31, M31, M31, M31]); }
+  set(i: number, v: QM31): void { v.to_m31_array().forEach((m, k) => this.columns[k]!.set(i, m)); }
   to_vec(): QM31[] {
     const c = this.columns.map((x) => x.toU32());
     return Array.from({ length: this.len() }, (_, i) => QM31.from_u32_unchecked(c[0]![i]!, c[1]![i]!, c[2]![i]!, c[3]![i]!));
   }
+  toCpu(): QM31[] { return this.to_vec(); }
 }
 
 export class HipBackend implements Backend {
@@ -79,6 +96,73 @@ export class HipBackend implements Backend {
     check(hip.tstwo_m31_batch_inverse(col.dev, out.dev, BigInt(col.len())));
     return out;
   }
+  batchInverseSecure(col: HipSecureColumn): HipSecureColumn {
+    const out = HipSecureColumn.uninitialized(col.len());
+    check(hip.tstwo_qm31_batch_inverse(ptr(col.ptrs()), ptr(out.ptrs()), BigInt(col.len())));
+    return out;
+  }
+  /** Many small inversions in one phase: enqueue them with the *_async entry points and ask ONCE (tstwo_check_zero_flag). */
+  batchInverseDeferred(col: HipColumn): HipColumn {
+    const out = HipColumn.uninitialized(col.len());
+    check(hip.tstwo_m31_batch_inverse_async(col.dev, out.dev, BigInt(col.len())));
+    return out;
+  }
+  checkNoZeroInverse(): void { check(hip.tstwo_check_zero_flag()); }     // throws "0 has no inverse"
+  // QuotientOps / AccumulationOps (backend/index.ts:82-91 leaves them empty; the functions live in backend/cpu/*.ts)
+  accumulateQuotients = accumulateQuotients;
+  accumulate = accumulate;
+  generate_secure_powers = generate_secure_powers;
+}
+
+/** accumulateQuotients (backend/cpu/quotients.ts:52-75) on device columns.  The per-batch constants come from the reference's OWN
+ *  quotientConstants() and the denominators are read the way its denominatorInverses() reads them (Pr / Pi = c0.real / c0.imag,
+ *  quotients.ts:160-178), so the rows equal CpuBackend's bit for bit; `rustSemantics` switches to stwo's definitions
+ *  (conj(a + bu) = a - bu, Pr = c0, Pi = c1), computed inside the library (tstwo_quotients_accumulate_samples). */
+export function accumulateQuotients(
+  domain: CircleDomain,
+  columns: Array<HipCircleEvaluation>,
+  random_coeff: QM31,
+  sample_batches: ColumnSampleBatch[],
+  _log_blowup_factor: number,
+  rustSemantics = false,
+): SecureEvaluation<HipBackend, BitReversedOrder> {
+  const n = domain.size();
+  columns.forEach((c) => { if (c.dev.len() !== n) throw new Error("column length does not match the domain size"); });
+  const out = HipSecureColumn.uninitialized(n);
+  const off = [0], cidx: number[] = [];
+  sample_batches.forEach((sb) => { sb.columns_and_values.forEach(([ci]) => cidx.push(ci)); off.push(cidx.length); });
+  const colPtrs = ptr(ptrs(columns.map((c) => c.dev.dev)));
+  if (rustSemantics) {
+    const points = sample_batches.flatMap((sb) => [...q4(sb.point.x), ...q4(sb.point.y)]);
+    const values = sample_batches.flatMap((sb) => sb.columns_and_values.flatMap(([, v]) => [...q4(v)]));
+    check(hip.tstwo_quotients_accumulate_samples(domain.halfCoset.initial_index.value, domain.log_size(), colPtrs, BigInt(columns.length),
+      BigInt(sample_batches.length), ptr(u32s(off)), ptr(u32s(cidx)), ptr(u32s(points)), ptr(u32s(values)), ptr(q4(random_coeff)), ptr(out.ptrs())));
+    return new SecureEvaluation(domain, out as any);
+  }
+  const qc = quotientConstants(sample_batches, random_coeff);
+  const abc = qc.line_coeffs.flatMap((lc) => lc.flatMap(([a, b, c]) => [...q4(a), ...q4(b), ...q4(c)]));
+  const bco = qc.batch_random_coeffs.flatMap((c) => [...q4(c)]);
+  const real = (m: M31): number[] => [m.value, 0];                      // an M31 as a CM31 (value, 0)
+  const prx = sample_batches.flatMap((sb) => real(sb.point.x.c0.real)), pry = sample_batches.flatMap((sb) => real(sb.point.y.c0.real));
+  const pix = sample_batches.flatMap((sb) => real(sb.point.x.c0.imag)), piy = sample_batches.flatMap((sb) => real(sb.point.y.c0.imag));
+  check(hip.tstwo_quotients_accumulate(domain.halfCoset.initial_index.value, domain.log_size(), colPtrs, BigInt(columns.length),
+    BigInt(sample_batches.length), ptr(u32s(off)), ptr(u32s(cidx)), ptr(u32s(abc)), ptr(u32s(bco)),
+    ptr(u32s(prx)), ptr(u32s(pry)), ptr(u32s(pix)), ptr(u32s(piy)), ptr(out.ptrs())));        // throws "0 has no inverse"
+  return new SecureEvaluation(domain, out as any);
+}
+
+/** AccumulationOps.accumulate (backend/cpu/accumulation.ts:38-49): column[i] += other[i]. */
+export function accumulate(column: HipSecureColumn, other: HipSecureColumn): void {
+  if (column.len() !== other.len()) throw new Error("column length mismatch");
+  check(hip.tstwo_secure_accumulate(ptr(column.ptrs()), ptr(other.ptrs()), BigInt(column.len())));
+}
+
+/** generate_secure_powers (accumulation.ts:52-63): a handful of scalars, host side like the reference. */
+export function generate_secure_powers(felt: QM31, nPowers: number): QM31[] {
+  const res: QM31[] = [];
+  let acc = QM31.one();
+  for (let i = 0; i < nPowers; i++) { res.push(acc); acc = acc.mul(felt); }
+  return res;
 }
 
 /** TwiddleTree with device buffers; generated on the GPU (backend/cpu/circle.ts:210-239). */
@@ -187,26 +271,61 @@ export class HipFriOps {
   }
 }
 
-/** MerkleOps<Blake2sHash>: layers stay in HBM; hashNode semantics (children AND the layer's column values). */
-export class HipMerkleOps {
-  commitOnLayer(logSize: number, prevLayer: DeviceBuffer | undefined, columns: readonly HipColumn[]): DeviceBuffer {
+/** MerkleOps<Blake2sHash> EXACTLY as vcs/ops.ts:16-26 declares it, so `MerkleProver.commit(new HipMerkleOps(), columns)`
+ *  (vcs/prover.ts:13-30) type-checks and runs unchanged: hashes and column values cross the boundary as host objects, one layer
+ *  per call (hashNode semantics: children AND the layer's column values, vcs/blake2_merkle.ts:9-24).  A column that is a
+ *  HipColumn (see its `length` getter) is hashed where it lives; a plain M31[] is uploaded first.  This is the compatibility
+ *  path — a prover that keeps its trace in HBM uses HipMerkleProver below, which never brings a layer to the host. */
+export class HipMerkleOps implements MerkleOps<Blake2sHash> {
+  commitOnLayer(logSize: number, prevLayer: readonly Blake2sHash[] | undefined, columns: readonly (readonly M31[])[]): Blake2sHash[] {
+    const n = 1 << logSize;
+    const devCols = columns.map((c) => ((c as unknown) instanceof HipColumn ? (c as unknown as HipColumn) : HipColumn.fromArray(c)));
+    devCols.forEach((c) => { if (c.len() !== n) throw new Error("column length does not match the layer size"); });
+    let prev: DeviceBuffer | undefined;
+    if (prevLayer !== undefined) {
+      if (prevLayer.length !== 2 * n) throw new Error("previous layer must have twice as many hashes");
+      const bytes = new Uint8Array(64 * n);
+      prevLayer.forEach((h, i) => bytes.set(h.bytes, 32 * i));
+      prev = new DeviceBuffer(64 * n);
+      prev.upload(bytes);
+    }
+    const out = this.commitOnLayerDevice(logSize, prev, devCols);
+    const flat = out.downloadBytes(32 * n);
+    return Array.from({ length: n }, (_, i) => new Blake2sHash(flat.subarray(32 * i, 32 * i + 32)));
+  }
+  /** The same on device buffers (prevLayer: 2^(logSize+1) digests of 32 bytes; result: 2^logSize digests). */
+  commitOnLayerDevice(logSize: number, prevLayer: DeviceBuffer | undefined, columns: readonly HipColumn[]): DeviceBuffer {
     const out = new DeviceBuffer(32 << logSize);
     check(hip.tstwo_merkle_commit_layer(logSize, prevLayer ? prevLayer.dev : 0n, ptr(ptrs(columns.map((c) => c.dev))), BigInt(columns.length), out.dev));
     return out;
   }
-  /** MerkleProver.commit: every layer, root first (layer k at byte 32*(2^k-1)), plus the 32-byte root on the host. */
-  commit(columns: readonly HipColumn[]): { layers: DeviceBuffer; root: Uint8Array } {
-    const logs = columns.map((c) => Math.log2(c.len()));
+}
+
+/** Device-resident replacement for MerkleProver<Blake2sHash> (vcs/prover.ts): commit / root / decommit with every layer kept in
+ *  HBM (layer k at byte 32*(2^k-1) of one buffer).  Columns of mixed sizes join at their layer, input order kept within a size
+ *  class, like MerkleProver.commit's stable sort. */
+export class HipMerkleProver {
+  private constructor(readonly layers: DeviceBuffer, readonly maxLog: number, private readonly rootBytes: Uint8Array) {}
+  static commit(columns: readonly HipColumn[]): HipMerkleProver {
+    const logs = columns.map((c) => {
+      const lg = Math.log2(c.len());
+      if (!Number.isInteger(lg)) throw new Error("length is not power of two");
+      return lg;
+    });
     const maxLog = columns.length ? Math.max(...logs) : 0;
     const layers = new DeviceBuffer(32 * ((2 << maxLog) - 1)), root = new Uint8Array(32);
     check(hip.tstwo_merkle_commit(ptr(ptrs(columns.map((c) => c.dev))), ptr(u32s(logs)), BigInt(columns.length), layers.dev, ptr(root)));
-    return { layers, root };
+    return new HipMerkleProver(layers, maxLog, root);
   }
+  root(): Blake2sHash { return new Blake2sHash(this.rootBytes); }
+  /** Device address of the root: tstwo_channel_mix_root_draw_felt / tstwo_allgather_roots read it without a host round trip. */
+  rootDev(): bigint { return this.layers.dev; }
   /** MerkleProver.decommit (vcs/prover.ts:32-109) on a tree built by commit(): the walk and both gathers run in the library. */
-  decommit(layers: DeviceBuffer, columns: readonly HipColumn[], queriesPerLogSize: Map<number, number[]>):
-      { queriedValues: M31[]; hashWitness: Uint8Array[]; columnWitness: M31[] } {
+  decommit(queriesPerLogSize: ReadonlyMap<number, number[]>, columns: readonly HipColumn[]):
+      [M31[], { hashWitness: Blake2sHash[]; columnWitness: M31[] }] {
+    const layers = this.layers;
     const logs = columns.map((c) => Math.log2(c.len()));
-    const maxLog = columns.length ? Math.max(...logs) : 0;
+    const maxLog = this.maxLog;
     const sets = [...queriesPerLogSize].filter(([, q]) => q.length > 0);
     const totalQ = sets.reduce((a, [, q]) => a + q.length, 0);
     const capV = Math.max(1, totalQ * Math.max(1, columns.length)), capH = Math.max(1, 2 * totalQ * (maxLog + 1));
@@ -219,10 +338,31 @@ export class HipMerkleOps {
       ptr(u32s(sets.map(([lg]) => lg))), ptr(qPtrs), ptr(nQ), BigInt(sets.length),
       ptr(queried), ptr(counts.subarray(0, 1)), ptr(hashes), ptr(counts.subarray(1, 2)), ptr(colWit), ptr(counts.subarray(2, 3))));
     const [nq, nh, nw] = [Number(counts[0]), Number(counts[1]), Number(counts[2])];
-    return {
-      queriedValues: Array.from(queried.subarray(0, nq), (v) => M31.from_u32_unchecked(v)),
-      hashWitness: Array.from({ length: nh }, (_, i) => hashes.slice(32 * i, 32 * i + 32)),
-      columnWitness: Array.from(colWit.subarray(0, nw), (v) => M31.from_u32_unchecked(v)),
-    };
+    return [
+      Array.from(queried.subarray(0, nq), (v) => M31.from_u32_unchecked(v)),
+      { hashWitness: Array.from({ length: nh }, (_, i) => new Blake2sHash(hashes.slice(32 * i, 32 * i + 32))),
+        columnWitness: Array.from(colWit.subarray(0, nw), (v) => M31.from_u32_unchecked(v)) },
+    ];
   }
+}
+
+/** The one exchange of a column-sharded prover (SURVEY.md 8e; include/tstwo_hip.h "multi-GPU"): one Bun process per GPU,
+ *  the RCCL unique id handed from rank 0 to the others by any host channel (a file, a socket, an env variable). */
+export class HipComm {
+  private constructor(readonly rank: number, readonly world: number) {}
+  static uniqueId(): Uint8Array { const id = new Uint8Array(128); check(hip.tstwo_comm_unique_id(ptr(id))); return id; }
+  static init(rank: number, world: number, id: Uint8Array): HipComm {
+    ensureInit();
+    check(hip.tstwo_comm_init(rank, world, ptr(id)));
+    return new HipComm(rank, world);
+  }
+  /** All-gather of the trees' roots in rank order = stwo's TreeVec order (pcs/prover.ts:62-64,227-228). */
+  allgatherRoots(tree: HipMerkleProver): Blake2sHash[] {
+    const out = new DeviceBuffer(32 * this.world);
+    check(hip.tstwo_allgather_roots(tree.rootDev(), out.dev));
+    const flat = out.downloadBytes(32 * this.world);
+    out.free();
+    return Array.from({ length: this.world }, (_, r) => new Blake2sHash(flat.subarray(32 * r, 32 * r + 32)));
+  }
+  close(): void { check(hip.tstwo_comm_destroy()); }
 }

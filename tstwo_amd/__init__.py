@@ -30,3 +30,4 @@ from .vcs import (Blake2sMerkleHasher, DeviceHashLayer, HipMerkleOps, MerkleDeco
                   MerkleVerifier)
 
 __all__ = [n for n in dir() if not n.startswith("_")]
+from .semantics import get_semantics, set_semantics  # noqa: F401,E402

@@ -17,14 +17,15 @@ class Blake2sChannel:
     (blake2.ts:177-184), so every second challenge does not depend on what was mixed since — Rust draws 8 fresh base felts
     per draw_felt and drops 4.  Default = Rust (sound Fiat-Shamir); ts_compat=True reproduces the TS queue."""
 
-    def __init__(self, ts_compat: bool = False):
+    def __init__(self, ts_compat=None):
         self._digest = bytes(32)              # Blake2sHash default: all zeros (blake2.ts:42-49)
         self.n_challenges = 0
         self.n_sent = 0
-        self.ts_compat = ts_compat
+        from .semantics import ts_compat as _resolve
+        self.ts_compat = _resolve(ts_compat)        # None -> tstwo_amd.set_semantics() (default "rust")
         self._base_queue = []
 
-    create = classmethod(lambda cls, ts_compat=False: cls(ts_compat))
+    create = classmethod(lambda cls, ts_compat=None: cls(ts_compat))
 
     def digest(self) -> bytes:
         return self._digest

@@ -25,7 +25,7 @@ class CirclePoint:
     neg = conjugate
     def antipode(self): return CirclePoint(self.x.neg(), self.y.neg())
 
-    def complexConjugate(self, ts_compat=False):
+    def complexConjugate(self, ts_compat=None):
         return CirclePoint(self.x.complexConjugate(ts_compat), self.y.complexConjugate(ts_compat))
 
     def mul(self, scalar: int, one, zero):

@@ -176,9 +176,10 @@ class QM31:
         di = denom.inverse()
         return QM31(self.c0.mul(di), self.c1.mul(di).neg())
 
-    def complexConjugate(self, ts_compat: bool = False):
+    def complexConjugate(self, ts_compat=None):
         """Rust: (c0, -c1).  The TS port conjugates each CM31 instead (qm31.ts:433-435): ts_compat=True."""
-        if ts_compat:
+        from .semantics import ts_compat as _resolve
+        if _resolve(ts_compat):
             return QM31(self.c0.complexConjugate(), self.c1.complexConjugate())
         return QM31(self.c0, self.c1.neg())
 

@@ -275,6 +275,12 @@ class FriProver:
         # until the last layer.  Otherwise: the host channel, one 32-byte read-back per layer.
         on_device = (device_channel and not getattr(channel, "ts_compat", False) and hasattr(channel, "_digest")
                      and FriProver._device_capable(columns, twiddles))
+        if device_channel and getattr(channel, "ts_compat", False):
+            # the device channel implements Rust's draw_felt only: say so instead of silently taking the slower path
+            import warnings
+            warnings.warn("FriProver.commit: a ts-compatible channel (draw_felt queue, channel/blake2.ts:177-184) keeps the "
+                          "transcript on the host: one 32-byte root read-back per FRI layer instead of the device channel",
+                          RuntimeWarning, stacklevel=2)
         if on_device:
             dch = DeviceChannel(channel)
             alphas = L.DeviceBuffer(16 * (columns[0].domain.logSize() + 2))

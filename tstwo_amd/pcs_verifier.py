@@ -18,10 +18,17 @@ class VerificationError(Exception):
 
 
 def denominator_inverses(sample_batches, domain_point) -> list:
-    """backend/cpu/quotients.ts:160-178 (Rust semantics: Pr = c0, Pi = c1 of the sample point)."""
+    """backend/cpu/quotients.ts:160-178.  Rust semantics: Pr = c0, Pi = c1 of the sample point; under
+    tstwo_amd.set_semantics("ts") the TS port's reading (c0.real / c0.imag as real CM31s), like the prover side."""
+    from .semantics import ts_compat
     out = []
     for sb in sample_batches:
-        prx, pry, pix, piy = sb.point.x.c0, sb.point.y.c0, sb.point.x.c1, sb.point.y.c1
+        if ts_compat():
+            z = M31.zero()
+            prx, pry = CM31(sb.point.x.c0.real, z), CM31(sb.point.y.c0.real, z)
+            pix, piy = CM31(sb.point.x.c0.imag, z), CM31(sb.point.y.c0.imag, z)
+        else:
+            prx, pry, pix, piy = sb.point.x.c0, sb.point.y.c0, sb.point.x.c1, sb.point.y.c1
         px, py = CM31(domain_point.x, M31.zero()), CM31(domain_point.y, M31.zero())
         out.append(prx.sub(px).mul(piy).sub(pry.sub(py).mul(pix)).inverse())
     return out

@@ -308,11 +308,12 @@ class SecureCirclePoly:
         """secure_poly.ts:20-22 — one batched launch for the 4 coordinates."""
         return HipCirclePoly.eval_at_point_batch(self.polys, point)
 
-    def evalAtPoint(self, point, ts_compat: bool = False) -> QM31:
+    def evalAtPoint(self, point, ts_compat=None) -> QM31:
         """Rust: from_partial_evals of the coordinate evaluations.  The TS port returns coordinate 0 only
         (secure_poly.ts:14-18): ts_compat=True reproduces that."""
         cols = self.evalColumnsAtPoint(point)
-        return cols[0] if ts_compat else QM31.from_partial_evals(cols)
+        from .semantics import ts_compat as _resolve
+        return cols[0] if _resolve(ts_compat) else QM31.from_partial_evals(cols)
 
     eval_at_point, eval_columns_at_point = evalAtPoint, evalColumnsAtPoint
 

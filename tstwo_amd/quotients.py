@@ -10,6 +10,7 @@ from .backend import SecureColumnByCoords
 from .circle import CircleDomain, CirclePoint
 from .fields import CM31, M31, QM31, as_q4
 from .poly import HipCircleEvaluation, SecureEvaluation
+from .semantics import ts_compat as _resolve
 
 
 @dataclass
@@ -19,7 +20,7 @@ class ColumnSampleBatch:
     columns_and_values: list                # [(column_index, QM31)]
 
 
-def complexConjugateLineCoeffs(point: CirclePoint, value: QM31, alpha: QM31, ts_compat: bool = False):
+def complexConjugateLineCoeffs(point: CirclePoint, value: QM31, alpha: QM31, ts_compat=None):
     """constraints.ts:117-128."""
     if point.y == point.y.complexConjugate(ts_compat):
         raise ValueError("Cannot evaluate a line with a single point")
@@ -29,7 +30,7 @@ def complexConjugateLineCoeffs(point: CirclePoint, value: QM31, alpha: QM31, ts_
     return alpha.mul(a), alpha.mul(b), alpha.mul(c)
 
 
-def quotientConstants(sample_batches, random_coeff: QM31, ts_compat: bool = False):
+def quotientConstants(sample_batches, random_coeff: QM31, ts_compat=None):
     """columnLineCoeffs + batchRandomCoeffs (quotients.ts:124-152,183-191)."""
     line_coeffs, batch_coeffs = [], []
     for sb in sample_batches:
@@ -42,9 +43,10 @@ def quotientConstants(sample_batches, random_coeff: QM31, ts_compat: bool = Fals
     return line_coeffs, batch_coeffs
 
 
-def marshal_quotient_args(domain: CircleDomain, columns, random_coeff: QM31, sample_batches, ts_compat: bool = False):
+def marshal_quotient_args(domain: CircleDomain, columns, random_coeff: QM31, sample_batches, ts_compat=None):
     """Host-side part of accumulateQuotients: quotientConstants() + flattening into the C ABI's arrays.
     Returns (vals, args) where args is the argument tuple of tstwo_quotients_accumulate minus the output."""
+    ts_compat = _resolve(ts_compat)
     line_coeffs, batch_coeffs = quotientConstants(sample_batches, random_coeff, ts_compat)
     off, cidx, abc, bco, prx, pry, pix, piy = [0], [], [], [], [], [], [], []
     zero = M31.zero()
@@ -71,10 +73,11 @@ def marshal_quotient_args(domain: CircleDomain, columns, random_coeff: QM31, sam
 
 
 def accumulateQuotients(domain: CircleDomain, columns, random_coeff: QM31, sample_batches, _log_blowup_factor: int = 1,
-                        ts_compat: bool = False) -> SecureEvaluation:
+                        ts_compat=None) -> SecureEvaluation:
     """accumulateQuotients (quotients.ts:52-75).  Default = Rust semantics (QM31 conjugation (c0,-c1); Pr/Pi = the
     c0/c1 parts of the sample point).  ts_compat=True reproduces the TS port's deviations (per-CM31 conjugation,
     qm31.ts:433-435; Pr/Pi taken from c0.real/c0.imag, quotients.ts:168-174) — see DESIGN.md "reference quirks"."""
+    ts_compat = _resolve(ts_compat)
     out = SecureColumnByCoords.uninitialized(domain.size())
     if ts_compat:
         _vals, args = marshal_quotient_args(domain, columns, random_coeff, sample_batches, ts_compat)
