@@ -33,8 +33,10 @@ sys.path.insert(0, ROOT)
 
 LOG_SIZE = 22
 COLS_PER_GPU = 32
-VALU_PER_BUTTERFLY = 11.6      # measured: (115.3M + 153.2M wave instr) * 64 / (32 cols * 22 layers * 2^21)
-VALU_PEAK = 256 * 4 * 16 * 2.4e9
+VALU_PER_BUTTERFLY = 11.6      # measured: (113.7M + 153.6M wave instr) * 64 / (32 cols * 22 layers * 2^21), profiles/r02_sq_counters.json
+VALU_PEAK = 256 * 4 * 16 * 2.4e9          # nominal: one wave64 VALU instruction per SIMD per 4 cycles at 2.4 GHz
+VALU_PEAK_MEASURED = 35.3e12              # what a pure integer-VALU kernel sustains on this part (the clock settles near 2.16 GHz
+                                          # under VALU load): tools/microbench2.hip, profiles/r02_microbench.json
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -303,16 +305,18 @@ def main():
             "merkle_ms": merkle_ms,
             "merkle_GBps": merkle_bytes / (merkle_ms * 1e-3) / 1e9,
             "merkle_frac_of_hbm_peak": merkle_bytes / (merkle_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9> + fast::k_cfft_b<false,13> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9,0,14> + fast::k_cfft_b<false,13,false> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": passes, "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          # the kernel is VALU-bound, so the lane-op rate is reported next to the HBM fraction.
-                         # 11.2-12.2 VALU instructions per butterfly (profiles/r01_cfft_sq_counters.json), 39.3e12 lane-ops/s
-                         # = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz.
+                         # 11.3-12.2 VALU instructions per butterfly (profiles/r02_sq_counters.json); nominal peak 39.3e12
+                         # lane-ops/s = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz, measured 35.3e12.
                          "valu": {"instr_per_butterfly": VALU_PER_BUTTERFLY, "peak_lane_ops_per_s": VALU_PEAK,
                                   "achieved_lane_ops_per_s": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3),
-                                  "frac": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK}},
+                                  "frac": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK,
+                                  "measured_peak_lane_ops_per_s": VALU_PEAK_MEASURED,
+                                  "frac_of_measured_peak": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK_MEASURED}},
             "device": L.device_name(),
         }
         root_ok = None

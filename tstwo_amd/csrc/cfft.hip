@@ -568,6 +568,7 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
             }
         }
     }
+    if (const char *e = getenv("TSTWO_CFFT_LOGTA")) { if (atoi(e) >= 12 && atoi(e) <= 14) logta = (u32)atoi(e); }   // experiments
     int np = n >= kMaxLogTileB ? plan_passes(n, passes, kb, ka_max, logta) : plan_passes(n, passes);
     for (size_t i = 0; i < n_cols; i++)
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
