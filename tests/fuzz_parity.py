@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-oracle parity sweep (not collected by pytest; run on a GPU box: python tests/fuzz_parity.py --seconds 120).
+"""Randomised GPU-vs-oracle parity sweep.  tests/test_gpu_fuzz.py runs a fixed-seed slice of it in the -m gpu suite; longer sweeps:
+python tests/fuzz_parity.py --seconds 120 [--big] on a GPU box.
 Random shapes for the CFFT entry points (in place, out of place, fused extension, many columns), Merkle trees of mixed sizes,
 folds, batch inverses, bit reversal and quotients; every result must equal the CPU oracle bit for bit."""
 import argparse
@@ -18,13 +19,7 @@ from tstwo_amd import _lib as L  # noqa: E402
 import tstwo_amd as T  # noqa: E402
 from gpu_util import dev, host, p4, ptrs, vp  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--seconds", type=float, default=60)
-ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--big", action="store_true", help="only the large-size cases (tiled CFFT path, 13 <= log <= 22)")
-args = ap.parse_args()
-rng = np.random.default_rng(args.seed)
-L.init(0)
+rng = np.random.default_rng(0)         # re-seeded by run()
 P = L.P
 half_odds = lambda lg: 1 << (31 - (lg + 2))
 _tw_cache = {}
@@ -332,14 +327,31 @@ def case_merkle_big():
     return f"merkle_big {len(logs)} cols max log {mx}"
 
 
-cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs, case_quotients, case_eval_decommit_qm31,
-         case_rows_sharded]
-if args.big:
-    cases = [case_cfft_big, case_merkle_big]
-t0, done = time.time(), 0
-while time.time() - t0 < args.seconds:
-    msg = cases[done % len(cases)]()
-    done += 1
-    if done % (7 if args.big else 501) == 0:
-        print(f"[{time.time() - t0:6.1f}s] {done} cases ok (last: {msg})", flush=True)
-print(f"fuzz ok: {done} cases in {time.time() - t0:.1f}s, seed {args.seed}")
+def run(seconds=60.0, seed=0, big=False, max_cases=None, verbose=True):
+    """Round-robin over the case generators until `seconds` have passed or `max_cases` ran; returns the number of cases."""
+    global rng
+    rng = np.random.default_rng(seed)
+    _tw_cache.clear()
+    L.init(0)
+    cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs, case_quotients, case_eval_decommit_qm31,
+             case_rows_sharded]
+    if big:
+        cases = [case_cfft_big, case_merkle_big]
+    t0, done = time.time(), 0
+    while time.time() - t0 < seconds and (max_cases is None or done < max_cases):
+        msg = cases[done % len(cases)]()
+        done += 1
+        if verbose and done % (7 if big else 501) == 0:
+            print(f"[{time.time() - t0:6.1f}s] {done} cases ok (last: {msg})", flush=True)
+    if verbose:
+        print(f"fuzz ok: {done} cases in {time.time() - t0:.1f}s, seed {seed}")
+    return done
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", action="store_true", help="only the large-size cases (tiled CFFT path, 13 <= log <= 22)")
+    args = ap.parse_args()
+    run(args.seconds, args.seed, args.big)

@@ -1,0 +1,16 @@
+"""-m gpu: a fixed-seed slice of the randomised GPU-vs-oracle sweep (tests/fuzz_parity.py) inside the collected suite, so that
+the sweep's coverage — random shapes of every C-ABI entry point, random FRI / PCS configurations through prove -> verify — is
+re-run by the driver and not only by the builder.  Longer sweeps: python tests/fuzz_parity.py --seconds N [--big]."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fuzz_slice_small_shapes():
+    import fuzz_parity
+    assert fuzz_parity.run(seconds=60, seed=20261004, max_cases=4000, verbose=False) == 4000
+
+
+def test_fuzz_slice_tiled_sizes():
+    import fuzz_parity
+    assert fuzz_parity.run(seconds=120, seed=7, big=True, max_cases=40, verbose=False) == 40
