@@ -146,53 +146,11 @@ __device__ __forceinline__ qm31 eval_wg_sum(qm31 v, qm31 *scratch /* >= 4 entrie
     return v;
 }
 
-// E1: coefficients -> one partial per 4096-coefficient chunk.  grid = (chunks, columns).  n_coeffs < 4096 or unaligned
-// columns take the guarded scalar loads (coefficients beyond the polynomial count as zero).
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_eval_coeffs(ColPtrs cols, size_t n_coeffs, EvalW W, EvalF F, qm31 *__restrict__ partial_out,
-                                                    size_t out_stride) {
-    __shared__ qm31 tab[32 + 4];
+// Fold of up to 4096 QM31 partials by one workgroup (R = 16 per lane; fewer when `left` < 4096): entry i lives at
+// in[i * elem_stride].  The result is valid in lane 0.
+__device__ __forceinline__ qm31 eval_fold_partials(const qm31 *__restrict__ in, size_t elem_stride, size_t left, const EvalW &W, const EvalF &F,
+                                                   qm31 *tab) {
     const u32 t = threadIdx.x;
-    const u32 *__restrict__ c = colp(cols, blockIdx.y);
-    const size_t base = (size_t)blockIdx.x * 4096 + 4 * t;
-    uint4 x[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const size_t i = base + 1024 * (size_t)r;
-        if (FAST) {
-            x[r] = *reinterpret_cast<const uint4 *>(c + i);
-        } else {
-            x[r].x = i + 0 < n_coeffs ? c[i + 0] : 0u; x[r].y = i + 1 < n_coeffs ? c[i + 1] : 0u;
-            x[r].z = i + 2 < n_coeffs ? c[i + 2] : 0u; x[r].w = i + 3 < n_coeffs ? c[i + 3] : 0u;
-        }
-    }
-    eval_build_tables(tab, F);               // overlaps the loads above
-    __syncthreads();
-    const qm31 ft = qm31_mul(tab[t & 15], tab[16 + (t >> 4)]);
-    u32 ua = 0, ub = 0, uc = 0, ud = 0;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const u32 v[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
-        u64 a = ua, b = ub, cc = uc, d = ud;     // 4 products < 2^62 each + carry-in < 2^31: no overflow
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const qm31 w = W.w[4 * r + j];
-            a += (u64)v[j] * w.a; b += (u64)v[j] * w.b; cc += (u64)v[j] * w.c; d += (u64)v[j] * w.d;
-        }
-        ua = red64(a); ub = red64(b); uc = red64(cc); ud = red64(d);
-    }
-    qm31 v = qm31_mul(qm31{ua, ub, uc, ud}, ft);
-    v = eval_wg_sum(v, tab + 32);
-    if (t == 0) partial_out[(size_t)blockIdx.y * out_stride + blockIdx.x] = v;
-}
-
-// E2: QM31 partials -> one partial per 4096 of them (R = 16 per lane; fewer when m_in < 4096).  grid = (groups, columns).
-__global__ void __launch_bounds__(256) k_eval_partials(const qm31 *__restrict__ partial_in, size_t in_stride, size_t m_in, EvalW W, EvalF F,
-                                                      qm31 *__restrict__ partial_out, size_t out_stride) {
-    __shared__ qm31 tab[32 + 4];
-    const u32 t = threadIdx.x;
-    const qm31 *__restrict__ in = partial_in + (size_t)blockIdx.y * in_stride + (size_t)blockIdx.x * 4096;
-    const size_t left = m_in - (size_t)blockIdx.x * 4096;      // entries of this group (>= 1)
     eval_build_tables(tab, F);
     __syncthreads();
     const qm31 ft = qm31_mul(tab[t & 15], tab[16 + (t >> 4)]);
@@ -200,11 +158,82 @@ __global__ void __launch_bounds__(256) k_eval_partials(const qm31 *__restrict__ 
 #pragma unroll 4
     for (int r = 0; r < 16; r++) {
         const size_t i = (size_t)r * 256 + t;
-        if (i < left) acc = qm31_add(acc, qm31_mul(in[i], W.w[r]));
+        if (i < left) acc = qm31_add(acc, qm31_mul(in[i * elem_stride], W.w[r]));
     }
-    qm31 v = qm31_mul(acc, ft);
+    const qm31 v = qm31_mul(acc, ft);
+    return eval_wg_sum(v, tab + 32);
+}
+
+// E1: coefficients -> one partial per chunk of 4096 * G coefficients.  grid = (chunks, columns).  G = 4 (64 coefficients
+// per lane: the per-lane fixed work — lane factor, workgroup sum — is paid once per 64 instead of once per 16) when that still
+// leaves >= 2 workgroups per CU, else G = 1.  Group g of a chunk (index bits 12, 13) is folded with the uniform factors H[g].
+// n_coeffs < 4096 or unaligned columns take the guarded scalar loads (coefficients beyond the polynomial count as zero).
+struct EvalH { qm31 h[4]; };         // h[g] = prod_{bit of g} fac[12 + bit]  (h[0] = 1)
+// (A one-launch variant — the workgroup that arrives last on an agent-scope counter folds the partials itself, hand-off by the
+// CDNA guide's release / acquire recipe — was built and measured: 28.7 us instead of 25.5 for one column of 2^22, 93 instead
+// of 50 for 32 columns of 2^20: a release fence (L2 write-back) in every one of the 256 .. 2048 workgroups costs more than
+// the second launch it saves.  Removed.)
+template <bool FAST, int G>
+__global__ void __launch_bounds__(256) k_eval_coeffs(ColPtrs cols, size_t n_coeffs, EvalW W, EvalF F, EvalH H, qm31 *__restrict__ partial_out,
+                                                    size_t out_stride) {
+    __shared__ qm31 tab[32 + 4];
+    const u32 t = threadIdx.x;
+    const u32 *__restrict__ c = colp(cols, blockIdx.y);
+    const size_t base = (size_t)blockIdx.x * (4096 * G) + 4 * t;
+    auto load_group = [&](uint4 (&x)[4], int g) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t i = base + 4096 * (size_t)g + 1024 * (size_t)r;
+            if (FAST) {
+                x[r] = *reinterpret_cast<const uint4 *>(c + i);
+            } else {
+                x[r].x = i + 0 < n_coeffs ? c[i + 0] : 0u; x[r].y = i + 1 < n_coeffs ? c[i + 1] : 0u;
+                x[r].z = i + 2 < n_coeffs ? c[i + 2] : 0u; x[r].w = i + 3 < n_coeffs ? c[i + 3] : 0u;
+            }
+        }
+    };
+    uint4 x[4];
+    load_group(x, 0);
+    eval_build_tables(tab, F);               // overlaps the loads above
+    __syncthreads();
+    const qm31 ft = qm31_mul(tab[t & 15], tab[16 + (t >> 4)]);
+    qm31 total = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        uint4 y[4];
+        if (g + 1 < G) load_group(y, g + 1);       // next group's loads fly while this one is multiplied
+        u32 ua = 0, ub = 0, uc = 0, ud = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const u32 v[4] = {x[r].x, x[r].y, x[r].z, x[r].w};
+            u64 a = ua, b = ub, cc = uc, d = ud;     // 4 products < 2^62 each + carry-in < 2^31: no overflow
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const qm31 w = W.w[4 * r + j];
+                a += (u64)v[j] * w.a; b += (u64)v[j] * w.b; cc += (u64)v[j] * w.c; d += (u64)v[j] * w.d;
+            }
+            ua = red64(a); ub = red64(b); uc = red64(cc); ud = red64(d);
+        }
+        const qm31 u = {ua, ub, uc, ud};
+        total = g == 0 ? u : qm31_add(total, qm31_mul(u, H.h[g]));
+        if (g + 1 < G) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) x[r] = y[r];
+        }
+    }
+    qm31 v = qm31_mul(total, ft);
     v = eval_wg_sum(v, tab + 32);
     if (t == 0) partial_out[(size_t)blockIdx.y * out_stride + blockIdx.x] = v;
+}
+
+// E2: QM31 partials -> one partial per 4096 of them.  grid = (groups, columns).
+__global__ void __launch_bounds__(256) k_eval_partials(const qm31 *__restrict__ partial_in, size_t in_stride, size_t m_in, EvalW W, EvalF F,
+                                                      qm31 *__restrict__ partial_out, size_t out_stride) {
+    __shared__ qm31 tab[32 + 4];
+    const qm31 *__restrict__ in = partial_in + (size_t)blockIdx.y * in_stride + (size_t)blockIdx.x * 4096;
+    const size_t left = m_in - (size_t)blockIdx.x * 4096;      // entries of this group (>= 1)
+    const qm31 v = eval_fold_partials(in, 1, left, W, F, tab);
+    if (threadIdx.x == 0) partial_out[(size_t)blockIdx.y * out_stride + blockIdx.x] = v;
 }
 
 unsigned capped_blocks(size_t work_items, unsigned threads) {
@@ -428,11 +457,14 @@ static int eval_at_point_impl(const u32 *const *coeffs, size_t n_cols, u32 log_s
         for (int i = 0; i < 8; i++) F.f[i] = to_q(fac[lane_bit0 + i]);
     };
     const size_t n_coeffs = (size_t)1 << log_size;
-    const size_t chunks = log_size > 12 ? (size_t)1 << (log_size - 12) : 1;
+    // 64 coefficients per lane (G = 4) when the grid still has a workgroup per CU, else 16 (G = 1)
+    const u32 glog = (log_size >= 14 && (((size_t)1 << (log_size - 14)) * n_cols >= (size_t)c.n_cus)) ? 2u : 0u;
+    const u32 chunk_log = 12 + glog;
+    const size_t chunks = log_size > chunk_log ? (size_t)1 << (log_size - chunk_log) : 1;
     const size_t groups1 = chunks > 4096 ? chunks / 4096 : 1;
     bool aligned = true;
     for (size_t i = 0; i < n_cols; i++) aligned = aligned && ((((uintptr_t)coeffs[i]) & 15) == 0);
-    const bool fast = log_size >= 12 && aligned;
+    const bool fast = log_size >= chunk_log && aligned;
     const size_t kChunkCols = 32768;                       // gridDim.y limit
     for (size_t col0 = 0; col0 < n_cols; col0 += kChunkCols) {
         const size_t g = n_cols - col0 < kChunkCols ? n_cols - col0 : kChunkCols;
@@ -447,19 +479,25 @@ static int eval_at_point_impl(const u32 *const *coeffs, size_t n_cols, u32 log_s
         if (rc) return rc;
         EvalW W;
         EvalF F;
-        {   // E1: bits 0,1 (j) and 10,11 (r) through W[4 r + j]; bits 2..9 are the lane bits
-            const int wb[4] = {0, 1, 10, 11};
-            level_tables(wb, 2, W, F);
-            const size_t stride = chunks == 1 ? 1 : chunks;
-            qm31 *o = (chunks == 1 && host_dst) ? host_dst : bufA;
-            if (fast)
-                hipLaunchKernelGGL(k_eval_coeffs<true>, dim3((unsigned)chunks, (unsigned)g), dim3(256), 0, c.stream, cp, n_coeffs, W, F, o, stride);
-            else
-                hipLaunchKernelGGL(k_eval_coeffs<false>, dim3((unsigned)chunks, (unsigned)g), dim3(256), 0, c.stream, cp, n_coeffs, W, F, o, stride);
-        }
         qm31 *src = bufA, *dst = bufB;
         size_t m_in = chunks;
-        u32 bit0 = 12;
+        u32 bit0 = chunk_log;
+        {   // E1: bits 0,1 (j) and 10,11 (r) through W[4 r + j]; bits 2..9 are the lane bits; bits 12,13 the groups of a chunk
+            const int wb[4] = {0, 1, 10, 11};
+            level_tables(wb, 2, W, F);
+            EvalH H;
+            H.h[0] = to_q(one); H.h[1] = to_q(fac[12]); H.h[2] = to_q(fac[13]); H.h[3] = to_q(host::qmul(fac[12], fac[13]));
+            const size_t stride = chunks == 1 ? 1 : chunks;
+            qm31 *o = (chunks == 1 && host_dst) ? host_dst : bufA;
+            const dim3 grid((unsigned)chunks, (unsigned)g);
+            if (glog) {
+                if (fast) hipLaunchKernelGGL((k_eval_coeffs<true, 4>), grid, dim3(256), 0, c.stream, cp, n_coeffs, W, F, H, o, stride);
+                else hipLaunchKernelGGL((k_eval_coeffs<false, 4>), grid, dim3(256), 0, c.stream, cp, n_coeffs, W, F, H, o, stride);
+            } else {
+                if (fast) hipLaunchKernelGGL((k_eval_coeffs<true, 1>), grid, dim3(256), 0, c.stream, cp, n_coeffs, W, F, H, o, stride);
+                else hipLaunchKernelGGL((k_eval_coeffs<false, 1>), grid, dim3(256), 0, c.stream, cp, n_coeffs, W, F, H, o, stride);
+            }
+        }
         while (m_in > 1) {   // E2: 12 more bits per level (lane bits bit0..bit0+7, W over bit0+8..bit0+11)
             const int wb[4] = {(int)bit0 + 8, (int)bit0 + 9, (int)bit0 + 10, (int)bit0 + 11};
             level_tables(wb, bit0, W, F);
