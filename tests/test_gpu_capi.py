@@ -689,3 +689,51 @@ def test_quotients_from_samples_vs_oracle(log, golden):
     with pytest.raises(L.TstwoError, match="Cannot evaluate a line with a single point"):
         L.call("tstwo_quotients_accumulate_samples", half_odds(log - 1), log, ptrs(d), n_cols, 1, L.u32x([0, 1]), L.u32x([0]),
                L.u32x([1, 2, 3, 4, 5, 6, 0, 0]), L.u32x([1, 1, 1, 1]), L.u32x((1, 2, 3, 4)), p4(out))
+
+
+def test_quotient_batch_offsets_are_validated():
+    """batch_off sizes host buffers inside the library: it must start at 0 and never decrease (TSTWO_ERR_BAD_ARG otherwise,
+    nothing is launched)."""
+    n = 6
+    cols = [dev(rand_column(70 + c, 1 << n)) for c in range(2)]
+    out = [dev_empty(1 << n) for _ in range(4)]
+    pts = L.u32x([1, 0, 478637715, 513582971, 992285211, 649143431, 740191619, 1186584352] * 2)
+    vals = L.u32x([7, 8, 9, 10] * 4)
+    for bad, what in (([1, 2, 3], r"batch_off\[0\] must be 0"), ([0, 3, 2], "non-decreasing")):
+        with pytest.raises(L.TstwoError, match=what):
+            L.call("tstwo_quotients_accumulate_samples", half_odds(n - 1), n, ptrs(cols), 2, 2, L.u32x(bad), L.u32x([0, 1, 0, 1]), pts, vals,
+                   L.u32x([1, 2, 3, 4]), p4(out))
+    L.call("tstwo_quotients_accumulate_samples", half_odds(n - 1), n, ptrs(cols), 2, 2, L.u32x([0, 1, 2]), L.u32x([0, 1]), pts, vals,
+           L.u32x([1, 2, 3, 4]), p4(out))
+
+
+def test_allocator_modes_and_threads():
+    """tstwo_set_alloc_mode rejects unknown modes; tstwo_malloc / tstwo_free are safe from several threads at once (the pool is
+    behind a mutex: a finaliser thread may release blocks while another thread allocates)."""
+    import threading
+    with pytest.raises(L.TstwoError, match="unknown mode"):
+        L.call("tstwo_set_alloc_mode", 7)
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            held = []
+            for _ in range(400):
+                if held and rng.random() < 0.5:
+                    held.pop(int(rng.integers(0, len(held)))).free()
+                else:
+                    held.append(L.DeviceBuffer(int(rng.choice([16, 4096, 5000, 65536, 1 << 20]))))
+            ptrs_ = [b.ptr for b in held]
+            assert len(set(ptrs_)) == len(ptrs_)
+            for b in held:
+                b.free()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    L.call("tstwo_set_alloc_mode", L.ALLOC_POOL)
