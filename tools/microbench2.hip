@@ -143,6 +143,54 @@ __global__ void __launch_bounds__(256) k_bf16v(u32 *out, u32 seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// ---- what decides the rate inside a mixed stream?  (a) alternating fast / slow opcodes on independent registers,
+// (b) a fully dependent chain of the fast opcode, (c) the butterfly hand-interleaved 4 ways (instruction k of four independent
+// butterflies back to back), modulus in a VGPR: every instruction's inputs were produced >= 4 instructions earlier.
+#define I_ADDMIN(d) "v_add_u32 " d ", " d ", %8\n" "v_min_u32 " d ", " d ", %9\n"
+ASM_KERNEL(k_addmin, I_ADDMIN)
+__global__ void __launch_bounds__(256) k_addchain(u32 *out, u32 seed) {
+    u32 a0 = threadIdx.x + seed, b = a0 * 2654435761u + 1;
+#pragma unroll 1
+    for (int i = 0; i < ITERS; i++) {
+        asm volatile("v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
+                     "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n" : "+v"(a0) : "v"(b));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0;
+}
+// 4 butterflies (a_i = %0..%3, b_i = %4..%7); 64-bit temporaries in fixed registers v[200:207]; %8 = P (VGPR), %9 = doubled twiddle
+#define BF4(OP) OP("%0", "%4", "200", "201") OP("%1", "%5", "202", "203") OP("%2", "%6", "204", "205") OP("%3", "%7", "206", "207")
+#define S_MAD(a, b, lo, hi) "v_mad_u64_u32 v[" lo ":" hi "], vcc, " b ", %9, 0\n"
+#define S_LSHR(a, b, lo, hi) "v_lshrrev_b32 " b ", 1, v" lo "\n"
+#define S_ADDH(a, b, lo, hi) "v_add_u32 " b ", " b ", v" hi "\n"
+#define S_SUBP(a, b, lo, hi) "v_sub_u32 v" lo ", " b ", %8\n"
+#define S_MINM(a, b, lo, hi) "v_min_u32 " b ", " b ", v" lo "\n"
+#define S_APM(a, b, lo, hi) "v_add_u32 v" lo ", " a ", " b "\n"
+#define S_AMM(a, b, lo, hi) "v_sub_u32 v" hi ", " a ", " b "\n"
+#define S_APMP(a, b, lo, hi) "v_sub_u32 " b ", v" lo ", %8\n"
+#define S_MINA(a, b, lo, hi) "v_min_u32 " a ", v" lo ", " b "\n"
+#define S_AMMP(a, b, lo, hi) "v_add_u32 " b ", v" hi ", %8\n"
+#define S_MINB(a, b, lo, hi) "v_min_u32 " b ", v" hi ", " b "\n"
+#define BF_ROUND BF4(S_MAD) BF4(S_LSHR) BF4(S_ADDH) BF4(S_SUBP) BF4(S_MINM) BF4(S_APM) BF4(S_AMM) BF4(S_APMP) BF4(S_MINA) BF4(S_AMMP) BF4(S_MINB)
+__global__ void __launch_bounds__(256) k_bf_asm4(u32 *out, u32 seed) {
+    u32 a0 = (threadIdx.x + seed) & 0x3fffffffu, a1 = (a0 * 3) & 0x3fffffffu, a2 = (a0 * 5) & 0x3fffffffu, a3 = (a0 * 7) & 0x3fffffffu;
+    u32 b0 = (a0 + 11) & 0x3fffffffu, b1 = (a0 + 13) & 0x3fffffffu, b2 = (a0 + 17) & 0x3fffffffu, b3 = (a0 + 19) & 0x3fffffffu;
+    u32 P = 2147483647u;
+    u32 t2 = ((seed * 2654435761u) % 2147483647u) * 2;
+#pragma unroll 1
+    for (int i = 0; i < ITERS; i++) {      // 8 butterflies per iteration (two rounds of four)
+        asm volatile(BF_ROUND BF_ROUND
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)
+                     : "v"(P), "s"(t2) : "vcc", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ b0 ^ b1 ^ b2 ^ b3;
+}
+
 typedef void (*kern_t)(u32 *, u32);
 struct Entry { const char *name; kern_t k; double ops_per_iter; };
 
@@ -183,6 +231,9 @@ int main() {
         {"v_mad_u64_u32", k_mad64, 32}, {"v_mad_u64_u32_sgpr", k_mad64s, 32}, {"v_mad_u64_u32_zero_addend", k_mad64z, 32},
         {"m31_butterfly_compiled(11 instr)", k_bf16, 32.0 / 4},   // 32 butterflies per 4 ITERS-units
         {"m31_butterfly_compiled_P_in_vgpr", k_bf16v, 32.0 / 4},
+        {"alternating v_add_u32 / v_min_u32 (per instruction)", k_addmin, 64},
+        {"v_add_u32 fully dependent chain", k_addchain, 32},
+        {"m31_butterfly asm, 4-way interleaved, P in vgpr", k_bf_asm4, 8},
     };
     // warm up clocks
     for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_add, dim3(cus * 8), dim3(256), 0, 0, out, 1u);
