@@ -49,9 +49,9 @@ int load_rccl() {
     const char *names[] = {getenv("TSTWO_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *n : names)      // a copy already mapped by the process (PyTorch's) first
-        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
     for (const char *n : names)
-        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);       // private: symbols are taken with dlsym only
     if (!h) return set_error(TSTWO_ERR_COMM, std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so not found") +
                                                  " (set TSTWO_RCCL_LIB to its path)");
     Rccl r;
