@@ -76,8 +76,10 @@ int tstwo_zero(void *dev, size_t bytes);                                  /* asy
 /* hipGraph capture of a launch sequence (launch-bound loops: e.g. the 20+ small kernels of a FRI commit with the device
  * channel).  Between begin and end every asynchronous entry point is RECORDED on the library's stream instead of executed;
  * tstwo_graph_launch replays the recorded sequence with one call.  Rules while capturing: no entry point that returns data
- * to the host (they synchronise); allocations must hit the library's caching allocator (run the sequence once eagerly
- * first); all buffers the sequence uses must outlive the graph, which addresses them by value. */
+ * to the host (they synchronise) and none that uploads a host array (column tables beyond 64 pointers, gather requests,
+ * quotient constants: the staging slot they travel through is only valid at capture time); allocations must hit the
+ * library's caching allocator (run the sequence once eagerly first); all buffers the sequence uses must outlive the
+ * graph, which addresses them by value. */
 int tstwo_graph_begin_capture(void);
 int tstwo_graph_end_capture(void **graph_exec);
 int tstwo_graph_launch(void *graph_exec);

@@ -254,6 +254,7 @@ int tstwo_shutdown(void) {
     Context &c = g_ctx;
     if (!c.ready) return TSTWO_OK;
     (void)hipStreamSynchronize(c.stream);
+    (void)tstwo_comm_destroy();          // communicator and collective stream, if any
     {
         std::lock_guard<std::mutex> lock(g_pool.mu);
         (void)trim_locked();
