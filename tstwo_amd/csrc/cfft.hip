@@ -185,11 +185,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
     // ---- prefetch the first column's tile (16 bytes per lane per access)
     uint4 pf[kMaxV4];
     {
-        const u32 *__restrict__ data = colp(cols, col0);
+        const u32 *__restrict__ data = colp_u(cols, col0);
 #pragma unroll
         for (int it = 0; it < kMaxV4; it++) {
             const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
-            if (e < tile_words) pf[it] = *reinterpret_cast<const uint4 *>(data + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask));
+            if (e < tile_words) pf[it] = gload4(data + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask));
         }
     }
     // ---- twiddle heap: level lv (2^lv entries at twl[2^lv ..]) holds layer bit b = logt-1-lv, i.e. global
@@ -222,11 +222,11 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
         __syncthreads();
         // ---- prefetch the next column while this one is transformed
         if (col + 1 < col1) {
-            const u32 *__restrict__ next = colp(cols, col + 1);
+            const u32 *__restrict__ next = colp_u(cols, col + 1);
 #pragma unroll
             for (int it = 0; it < kMaxV4; it++) {
                 const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
-                if (e < tile_words) pf[it] = *reinterpret_cast<const uint4 *>(next + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask));
+                if (e < tile_words) pf[it] = gload4(next + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask));
             }
         }
         if (!INV) {
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
             }
         }
         // ---- LDS -> global (fused 2^-n scaling on interpolate's last pass)
-        u32 *__restrict__ data = colp(cols, col);
+        u32 *__restrict__ data = colp_u(cols, col);
 #pragma unroll
         for (int it = 0; it < kMaxV4; it++) {
             const u32 e = 4u * (threadIdx.x + (u32)it * THREADS);
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass
                     x.x = m31_mul(x.x, pp.scale); x.y = m31_mul(x.y, pp.scale);
                     x.z = m31_mul(x.z, pp.scale); x.w = m31_mul(x.w, pp.scale);
                 }
-                *reinterpret_cast<uint4 *>(data + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask)) = x;
+                gstore4(data + base + ((size_t)(e >> pp.c) << pp.lo) + (e & cmask), x);
             }
         }
         __syncthreads();
@@ -273,12 +273,12 @@ __global__ void k_cfft_small(ColPtrs cols, u32 n_cols, u32 n, u32 tx, u32 ty, u3
     if (col >= n_cols) return;
     u32 *v = colp(cols, col);
     if (n == 1) {
-        u32 v0 = v[0], v1 = v[1];
+        u32 v0 = gload1(v), v1 = gload1(v + 1);
         if (!INV) m31_butterfly(v0, v1, ty);
         else { m31_ibutterfly(v0, v1, ty); v0 = m31_mul(v0, scale); v1 = m31_mul(v1, scale); }
-        v[0] = v0; v[1] = v1;
+        gstore1(v, v0); gstore1(v + 1, v1);
     } else {
-        u32 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+        u32 v0 = gload1(v), v1 = gload1(v + 1), v2 = gload1(v + 2), v3 = gload1(v + 3);
         if (!INV) {
             m31_butterfly(v0, v2, tx); m31_butterfly(v1, v3, tx);
             m31_butterfly(v0, v1, ty); m31_butterfly(v2, v3, m31_neg(ty));
@@ -287,7 +287,7 @@ __global__ void k_cfft_small(ColPtrs cols, u32 n_cols, u32 n, u32 tx, u32 ty, u3
             m31_ibutterfly(v0, v2, tx); m31_ibutterfly(v1, v3, tx);
             v0 = m31_mul(v0, scale); v1 = m31_mul(v1, scale); v2 = m31_mul(v2, scale); v3 = m31_mul(v3, scale);
         }
-        v[0] = v0; v[1] = v1; v[2] = v2; v[3] = v3;
+        gstore1(v, v0); gstore1(v + 1, v1); gstore1(v + 2, v2); gstore1(v + 3, v3);
     }
 }
 
@@ -390,6 +390,7 @@ int allow_big_lds(const void *kernel) {
 
 template <typename KernelT, typename... Args>
 int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t tiles, u32 *const *cols, size_t n_cols, Args... args) {
+    // kernel signature: (ColPtrs cols, NoSrc, n_cols, total_items, args...)
     Context &c = ctx();
     {   // experiments: extra (unused) dynamic LDS per workgroup lowers the number of resident workgroups per CU
         static const int pad = [] { const char *e = getenv("TSTWO_CFFT_LDS_PAD"); return e ? atoi(e) : 0; }();
@@ -410,7 +411,7 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
         const size_t items = tiles * cnt;
         if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
         const unsigned blocks = plan_grid((const void *)kernel, threads, lds_bytes, items);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, c.stream, cp, (u32)cnt, (u32)items, args...);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, c.stream, cp, fast::NoSrc{}, (u32)cnt, (u32)items, args...);
     }
     TSTWO_LAUNCH_CHECK();
     if (getenv("TSTWO_CFFT_SYNC")) TSTWO_HIP(hipStreamSynchronize(c.stream));
@@ -421,8 +422,7 @@ template <bool INV, int K, int LOGTA = 14>
 int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, u32 scale) {
     const size_t tiles = (size_t)1 << (n - LOGTA);
     return launch_fast_kernel(fast::k_cfft_a<INV, K, 0, LOGTA>, 1 << (LOGTA - 4),
-                              ((size_t)(1 << LOGTA) + (1 << (LOGTA - 5)) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols, n, lo, tw_end, scale,
-                              fast::NoSrc{});
+                              ((size_t)(1 << LOGTA) + (1 << (LOGTA - 5)) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols, n, lo, tw_end, scale);
 }
 
 // First forward pass of an evaluation whose input is a smaller polynomial (log size n - EXT) in its own buffers.
@@ -442,7 +442,7 @@ int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, 
         const size_t items = tiles * cnt;
         if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
         const unsigned blocks = plan_grid((const void *)kernel, 1024, lds_bytes, items);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, c.stream, cp, (u32)cnt, (u32)items, n, lo, tw_end, 0u, sp);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(1024), lds_bytes, c.stream, cp, sp, (u32)cnt, (u32)items, n, lo, tw_end, 0u);
     }
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
@@ -469,9 +469,9 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         const size_t tiles = (size_t)1 << (n - ps.k);
         const size_t lds = (((size_t)1 << ps.k) + ((size_t)1 << (ps.k - 5)) + ((size_t)1 << (ps.k - 4))) * sizeof(u32);
         switch (ps.k) {
-            case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale, fast::NoSrc{});
-            case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale, fast::NoSrc{});
-            case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale, fast::NoSrc{});
+            case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale);
+            case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale);
+            case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale);
             default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported bottom pass");
         }
     }
@@ -656,8 +656,8 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
                 const size_t items = tiles * cnt;
                 if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
                 const unsigned blocks = plan_grid((const void *)kernel, 512, lds, items);
-                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, c.stream, cp, (u32)cnt, (u32)items, log_size, tw_end,
-                                   np == 1 ? n_inv : 0u, sp);
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, c.stream, cp, sp, (u32)cnt, (u32)items, log_size, tw_end,
+                                   np == 1 ? n_inv : 0u);
             }
             TSTWO_LAUNCH_CHECK();
         }

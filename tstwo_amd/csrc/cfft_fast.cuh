@@ -104,8 +104,8 @@ template <> struct SrcTable<0> { using type = NoSrc; };
 // (2^(LOGT-4) lanes).  LOGT = 13 is the default; smaller tiles give more workgroups when there are few columns.
 // OOP: tiles are read from `src` (left untouched) and written to `cols` — the first pass of an out-of-place interpolation.
 template <bool INV, int LOGT, bool OOP = false>
-__global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32 n_cols, u32 total_items, u32 n,
-                                                 const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<OOP ? 1 : 0>::type src) {
+__global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typename SrcTable<OOP ? 1 : 0>::type src, u32 n_cols, u32 total_items,
+                                                 u32 n, const u32 *__restrict__ tw_end, u32 scale) {
     constexpr int THREADS = 1 << (LOGT - 4);
     constexpr int GM = LOGT - 10;              // layers of the middle LDS stage (bits [8, LOGT-2))
     constexpr u32 T = 1u << LOGT, QT = T / 4;
@@ -127,44 +127,42 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
     item += col1 - col0;
     const size_t base = (size_t)hi << LOGT;
 
-    // twiddles of this lane's 16-word run for layers 1..3 (registers, doubled); layer 0 reuses layer 1's
-    u32 t1[4], t2[2], t3;
-    {
-        const uint4 q1 = *reinterpret_cast<const uint4 *>(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)) + 4 * t);
-        const uint2 q2 = *reinterpret_cast<const uint2 *>(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)) + 2 * t);
-        const u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << (LOGT - 4)) + t)];
-        t1[0] = q1.x + q1.x; t1[1] = q1.y + q1.y; t1[2] = q1.z + q1.z; t1[3] = q1.w + q1.w;
-        t2[0] = q2.x + q2.x; t2[1] = q2.y + q2.y;
-        t3 = q3 + q3;
-    }
-    // heap: level lv in 2..LOGT-5 holds layer bit b = LOGT-1 - lv
-    if (t >= 4) {
-        const u32 lv = 31u - (u32)__clz(t);
-        const u32 b = (u32)(LOGT - 1) - lv;
-        const u32 v = tw_end[-(ptrdiff_t)((size_t)1 << (n - b)) + (ptrdiff_t)(((size_t)hi << lv) + (t - (1u << lv)))];
-        twl[t] = v + v;
-    }
-    u32 ta, tb0, tb1;                                      // layer LOGT-1 / LOGT-2 twiddles (wave-uniform)
-    {
-        const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 1))) + (ptrdiff_t)hi];
-        const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
-        const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
-        ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
-    }
-
     auto src_of = [&](u32 col) -> const u32 * {
-        if constexpr (OOP) return colp(src, col) + base;
-        else return colp(cols, col) + base;
+        if constexpr (OOP) return colp_u<kSecondTableOff>(src, col) + base;
+        else return colp_u(cols, col) + base;
     };
+    // Workgroup start: EVERY global load of the prologue is issued back to back — the first tile, the lane's register
+    // twiddles (layers 1..3), its heap entry, the two top-layer twiddles — and only then is anything used.  A memory round
+    // trip costs ~2300 cycles here (s_memtime stamps); written in "load, use, load, use" order the compiler
+    // waited for each one in turn (five round trips, ~5 us per launch of a few-column transform).
     uint4 pf[4];
+    u32 t1[4], t2[2], t3, ta, tb0, tb1;
     {
         const u32 *__restrict__ d = src_of(col0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            pf[j] = *reinterpret_cast<const uint4 *>(d + (INV ? 16 * t + 4 * j : 4 * t + j * QT));
+            pf[j] = gload4(d + (INV ? 16 * t + 4 * j : 4 * t + j * QT));
+        uint4 q1 = gload4(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)) + 4 * t);
+        uint2 q2 = gload2(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)) + 2 * t);
+        u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << (LOGT - 4)) + t)];
+        // heap: level lv in 2..LOGT-5 holds layer bit b = LOGT-1 - lv (lanes 0..3 have no entry: they load lane 4's and drop it)
+        const u32 th = max(t, 4u);
+        const u32 lv = 31u - (u32)__clz(th);
+        const u32 hb = (u32)(LOGT - 1) - lv;
+        u32 hv = tw_end[-(ptrdiff_t)((size_t)1 << (n - hb)) + (ptrdiff_t)(((size_t)hi << lv) + (th - (1u << lv)))];
+        u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 1))) + (ptrdiff_t)hi];           // layer LOGT-1 / LOGT-2 (wave-uniform)
+        u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
+        u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
+        asm volatile("" : "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q3), "+v"(hv));   // one wait for all of them
+        t1[0] = q1.x + q1.x; t1[1] = q1.y + q1.y; t1[2] = q1.z + q1.z; t1[3] = q1.w + q1.w;
+        t2[0] = q2.x + q2.x; t2[1] = q2.y + q2.y;
+        t3 = q3 + q3;
+        if (t >= 4) twl[t] = hv + hv;
+        ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
     }
+
     for (u32 col = col0; col < col1; col++) {
-        u32 *__restrict__ data = colp(cols, col) + base;
+        u32 *__restrict__ data = colp_u(cols, col) + base;
         const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
         if (!INV) {
             top_layers<false, true>(pf, ta, tb0, tb1);                    // layers LOGT-1, LOGT-2
@@ -175,7 +173,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
             }
             lds_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + 4 * t + j * QT);
+            for (int j = 0; j < 4; j++) pf[j] = gload4(next + 4 * t + j * QT);
             lds_stage<GM, 8, LOGT, THREADS, false>(lds, twl);              // layers LOGT-3..8
             lds_barrier();
             lds_stage<4, 4, LOGT, THREADS, false>(lds, twl);               // layers 7..4
@@ -198,9 +196,9 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #ifdef TSTWO_EXP_B_STORE
-                *reinterpret_cast<uint4 *>(data + 4 * t + j * QT) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+                gstore4(data + 4 * t + j * QT, make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
 #else
-                *reinterpret_cast<uint4 *>(data + 16 * t + 4 * j) = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+                gstore4(data + 16 * t + 4 * j, make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
 #endif
             lds_barrier();
         } else {
@@ -223,7 +221,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
             for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
             lds_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(next + 16 * t + 4 * j);
+            for (int j = 0; j < 4; j++) pf[j] = gload4(next + 16 * t + 4 * j);
             lds_stage<4, 4, LOGT, THREADS, true>(lds, twl);
             lds_barrier();
             lds_stage<GM, 8, LOGT, THREADS, true>(lds, twl);
@@ -238,7 +236,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (scale) x[j] = scale4(x[j], scale);
-                *reinterpret_cast<uint4 *>(data + 4 * t + j * QT) = x[j];
+                gstore4(data + 4 * t + j * QT, x[j]);
             }
             lds_barrier();
         }
@@ -255,8 +253,8 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, u32
 // LOGT (12..14) = log2 of the tile: 2^(LOGT-4) lanes.  14 is the default; the smaller tiles exist for transforms of few
 // columns, where 2^(n-14) tiles would leave most of the 256 CUs without a workgroup.
 template <bool INV, int K, int EXT = 0, int LOGT = 14>
-__global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_cols, u32 total_items, u32 n, u32 lo,
-                                                const u32 *__restrict__ tw_end, u32 scale, typename SrcTable<EXT>::type src) {
+__global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typename SrcTable<EXT>::type src, u32 n_cols, u32 total_items, u32 n,
+                                                u32 lo, const u32 *__restrict__ tw_end, u32 scale) {
     static_assert(EXT == 0 || (!INV && K >= 2 && EXT <= 2), "fused extension: forward pass with two register layers");
     static_assert(LOGT >= 12 && LOGT <= 14 && LOGT - K >= 4, "strided tile: rows of at least 16 words");
     constexpr int THREADS = 1 << (LOGT - 4), C = LOGT - K;
@@ -285,27 +283,31 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
     // tile-relative word offset: < 2^(lo + K) <= 2^30 words (log_size <= 30), so 32 bits hold it
     auto goff = [&](u32 e) -> u32 { return ((e >> C) << lo) + (e & ((1u << C) - 1u)); };
 
-    if constexpr (R > 0) {
-        for (u32 idx = t; idx < (1u << K); idx += THREADS) {
-            if (idx >= (1u << F)) {
-                const u32 lv = 31u - (u32)__clz(idx);
-                const u32 i = lo + (K - 1 - lv);           // b = LOGT-1-lv, i = lo + b - C
-                const u32 v = tw_end[-(ptrdiff_t)((size_t)1 << (n - i)) + (ptrdiff_t)(((size_t)hi << lv) + (idx - (1u << lv)))];
-                twl[idx] = v + v;
-            }
+    // Twiddle staging (LDS heap for the stage layers, ta / tb for the register layers).  Called AFTER the first tile's loads
+    // have been issued: the heap fill waits for its own global loads, and a memory round trip costs ~2300 cycles here
+    // (s_memtime stamps), so tile loads issued behind it would pay that latency a second time.
+    u32 ta = 0, tb0 = 0, tb1 = 0;
+    auto stage_twiddles = [&]() {
+        static_assert((1 << K) <= THREADS, "one heap entry per lane at most");
+        u32 hv = 0;
+        if constexpr (R > 0) {      // unconditional load (lanes without an entry read entry 2^F and drop it): no branch around it
+            const u32 idx = min(max(t, (u32)(1 << F)), (u32)(1 << K) - 1u);
+            const u32 lv = 31u - (u32)__clz(idx);
+            const u32 i = lo + (K - 1 - lv);           // b = LOGT-1-lv, i = lo + b - C
+            hv = tw_end[-(ptrdiff_t)((size_t)1 << (n - i)) + (ptrdiff_t)(((size_t)hi << lv) + (idx - (1u << lv)))];
         }
-    }
-    if constexpr (INV && R > 0) lds_barrier();   // the inverse reads the heap in its first stage, before any other barrier
-    u32 ta, tb0 = 0, tb1 = 0;
-    {
         const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 1))) + (ptrdiff_t)hi];
-        ta = a + a;
+        u32 b0 = 0, b1 = 0;
         if constexpr (F == 2) {
-            const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
-            const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
-            tb0 = b0 + b0; tb1 = b1 + b1;
+            b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
+            b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (lo + K - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
         }
-    }
+        if constexpr (R > 0) {
+            asm volatile("" : "+v"(hv));
+            if (t >= (1u << F) && t < (1u << K)) twl[t] = hv + hv;
+        }
+        ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
+    };
     // element offsets of this lane's 16 words in the final-stage layout (R > 0)
     auto e_final = [&](u32 tt, int g, int m) -> u32 {
         const u32 gid = tt + (u32)g * THREADS;
@@ -321,21 +323,22 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
         auto load_tile = [&](const u32 *__restrict__ d) {
             if constexpr (EXT == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) pf[j] = *reinterpret_cast<const uint4 *>(d + goff(4 * t + j * QT));
+                for (int j = 0; j < 4; j++) pf[j] = gload4(d + goff(4 * t + j * QT));
             } else if constexpr (EXT == 1) {
-                pf[0] = *reinterpret_cast<const uint4 *>(d + goff(4 * t));
-                pf[1] = *reinterpret_cast<const uint4 *>(d + goff(4 * t + QT));
+                pf[0] = gload4(d + goff(4 * t));
+                pf[1] = gload4(d + goff(4 * t + QT));
             } else {
-                pf[0] = *reinterpret_cast<const uint4 *>(d + goff(4 * t));
+                pf[0] = gload4(d + goff(4 * t));
             }
         };
         auto src_of = [&](u32 col) -> const u32 * {
-            if constexpr (EXT == 0) return colp(cols, col) + base;
-            else return colp(src, col) + base;       // the first pass has hi == 0: base only carries bits below the replicated ones
+            if constexpr (EXT == 0) return colp_u(cols, col) + base;
+            else return colp_u<kSecondTableOff>(src, col) + base;       // the first pass has hi == 0: base only carries bits below the replicated ones
         };
         load_tile(src_of(col0));
+        stage_twiddles();
         for (u32 col = col0; col < col1; col++) {
-            u32 *__restrict__ data = colp(cols, col) + base;
+            u32 *__restrict__ data = colp_u(cols, col) + base;
             const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
             u32 tt = t;
             asm volatile("" : "+v"(tt));     // opaque per iteration: keeps the 16 scatter addresses out of loop-invariant registers
@@ -355,7 +358,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
                 for (int j = 0; j < 4; j++) {
                     uint4 x = pf[j];
                     if (INV && scale) x = scale4(x, scale);
-                    *reinterpret_cast<uint4 *>(data + goff(4 * t + j * QT)) = x;
+                    gstore4(data + goff(4 * t + j * QT), x);
                 }
                 load_tile(next);
             } else {
@@ -384,7 +387,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
                         *reinterpret_cast<uint4 *>(data + goff(4 * t + ((g * (1 << G2) + m) / 4) * QT)) = make_uint4(v[m], v[m + 1], v[m + 2], v[m + 3]);
 #else
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) data[goff(e_final(tt, g, m))] = v[m];
+                    for (int m = 0; m < (1 << G2); m++) gstore1(data + goff(e_final(tt, g, m)), v[m]);
 #endif
                 }
                 lds_barrier();
@@ -395,15 +398,17 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
         u32 pfs[16];
         {
             const u32 tt = t;
-            const u32 *__restrict__ d = colp(cols, col0) + base;
+            const u32 *__restrict__ d = colp_u(cols, col0) + base;
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = d[goff(e_final(tt, g, m))];
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(d + goff(e_final(tt, g, m)));
         }
+        stage_twiddles();
+        lds_barrier();       // the inverse reads the heap in its first stage, before any other barrier
         for (u32 col = col0; col < col1; col++) {
-            u32 *__restrict__ data = colp(cols, col) + base;
-            const u32 *__restrict__ next = colp(cols, min(col + 1, col1 - 1)) + base;
+            u32 *__restrict__ data = colp_u(cols, col) + base;
+            const u32 *__restrict__ next = colp_u(cols, min(col + 1, col1 - 1)) + base;
             u32 tt = t;
             asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -420,7 +425,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = next[goff(e_final(tt, g, m))];
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(next + goff(e_final(tt, g, m)));
             if constexpr (G1 > 0) {
                 lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl);
                 lds_barrier();
@@ -435,7 +440,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, u32 n_
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (scale) x[j] = scale4(x[j], scale);
-                *reinterpret_cast<uint4 *>(data + goff(4 * t + j * QT)) = x[j];
+                gstore4(data + goff(4 * t + j * QT), x[j]);
             }
             lds_barrier();
         }

@@ -70,7 +70,55 @@ constexpr int kMaxColsPerLaunch = 64;    // CFFT / bit-reverse batch chunk
 // (`ext`), so that a batch of thousands of small columns is still ONE launch instead of one per 64 columns.
 struct ColPtrs { u32 *p[kMaxColsPerLaunch]; u32 *const *ext; };
 #ifdef __HIPCC__
-__device__ __forceinline__ u32 *colp(const ColPtrs &c, u32 i) { return c.ext ? c.ext[i] : c.p[i]; }   // i is workgroup-uniform: a scalar load
+// Accesses to COLUMN data go through these: a column pointer comes out of a pointer table, so to the compiler it is a generic
+// address and a plain dereference is a flat_load / flat_store — vector-memory instructions that ALSO count on lgkmcnt, which
+// makes every LDS-only wait (s_waitcnt lgkmcnt(0) before s_barrier) wait for in-flight global traffic as well.  The explicit
+// global address space gives global_load / global_store (vmcnt only).
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
+#define TSTWO_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uint4 gload4(const u32 *p) {
+    const u32x4_t v = *(const TSTWO_GLOBAL u32x4_t *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 gload2(const u32 *p) {
+    const u32x2_t v = *(const TSTWO_GLOBAL u32x2_t *)p;
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ u32 gload1(const u32 *p) { return *(const TSTWO_GLOBAL u32 *)p; }
+__device__ __forceinline__ void gstore4(u32 *p, uint4 x) {
+    u32x4_t v;
+    v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+    *(TSTWO_GLOBAL u32x4_t *)p = v;
+}
+__device__ __forceinline__ void gstore1(u32 *p, u32 x) { *(TSTWO_GLOBAL u32 *)p = x; }
+// Column pointer i.  Written as a branch, not as `c.ext ? c.ext[i] : c.p[i]`: the compiler merged that into ONE load through a
+// selected generic address — a flat_load for the pointer and flat_loads for every column access derived from it.
+__device__ __forceinline__ u32 *colp(const ColPtrs &c, u32 i) {
+    u32 *p;
+    if (c.ext) {
+        asm volatile("");              // keeps the two loads in their own blocks (no if-conversion into a selected address)
+        p = c.ext[i];
+    } else {
+        p = c.p[i];                    // kernel-argument table
+    }
+    return p;
+}
+// The same for a wave-uniform i (every tiled kernel), as ONE scalar load: both tables are read through the constant address
+// space — the device table (written before the launch, read-only while the kernel runs) or the by-value table inside the
+// kernel-argument segment itself, which starts KERNARG_OFF bytes into it (0: ColPtrs is the first kernel argument; the
+// second table of the out-of-place / fused-extension passes follows it directly).  The pointer lands in SGPRs, so column
+// accesses (gload*/gstore*) are global_load / global_store with a scalar base, and nothing waits on vector memory for a pointer.
+template <int KERNARG_OFF = 0>
+__device__ __forceinline__ u32 *colp_u(const ColPtrs &c, u32 i) {
+    typedef const unsigned long long __attribute__((address_space(4))) *k64;
+    typedef const char __attribute__((address_space(4))) *kbytes;
+    const k64 tab = c.ext ? (k64)(unsigned long long)c.ext : (k64)((kbytes)__builtin_amdgcn_kernarg_segment_ptr() + KERNARG_OFF);
+    u32 *p = (u32 *)tab[(u32)__builtin_amdgcn_readfirstlane((int)i)];
+    // (the pointer itself is still "generic" to the compiler: dereference it through gload*/gstore* only)
+    return p;
+}
+constexpr int kSecondTableOff = (int)sizeof(ColPtrs);     // kernel signature (ColPtrs cols, <ColPtrs | NoSrc> src, ...)
 #endif
 // Host: describe columns [0, n_cols) of `cols` in `out`; slot 0/1 = which of the two device tables to use when a launch needs two.
 int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot);

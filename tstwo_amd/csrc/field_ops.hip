@@ -158,8 +158,8 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_v4(CSoa4 in, Soa4 ou
 #pragma unroll
     for (int g = 0; g < M; g++) {
         const size_t i = 4 * (t + (size_t)g * T);
-        const uint4 a = *reinterpret_cast<const uint4 *>(in.p[0] + i), b = *reinterpret_cast<const uint4 *>(in.p[1] + i);
-        const uint4 c = *reinterpret_cast<const uint4 *>(in.p[2] + i), d = *reinterpret_cast<const uint4 *>(in.p[3] + i);
+        const uint4 a = gload4(in.p[0] + i), b = gload4(in.p[1] + i);
+        const uint4 c = gload4(in.p[2] + i), d = gload4(in.p[3] + i);
         x[4 * g + 0] = {a.x, b.x, c.x, d.x}; x[4 * g + 1] = {a.y, b.y, c.y, d.y};
         x[4 * g + 2] = {a.z, b.z, c.z, d.z}; x[4 * g + 3] = {a.w, b.w, c.w, d.w};
     }
@@ -179,10 +179,10 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_v4(CSoa4 in, Soa4 ou
 #pragma unroll
     for (int g = 0; g < M; g++) {
         const size_t i = 4 * (t + (size_t)g * T);
-        *reinterpret_cast<uint4 *>(out.p[0] + i) = make_uint4(r[4 * g].a, r[4 * g + 1].a, r[4 * g + 2].a, r[4 * g + 3].a);
-        *reinterpret_cast<uint4 *>(out.p[1] + i) = make_uint4(r[4 * g].b, r[4 * g + 1].b, r[4 * g + 2].b, r[4 * g + 3].b);
-        *reinterpret_cast<uint4 *>(out.p[2] + i) = make_uint4(r[4 * g].c, r[4 * g + 1].c, r[4 * g + 2].c, r[4 * g + 3].c);
-        *reinterpret_cast<uint4 *>(out.p[3] + i) = make_uint4(r[4 * g].d, r[4 * g + 1].d, r[4 * g + 2].d, r[4 * g + 3].d);
+        gstore4(out.p[0] + i, make_uint4(r[4 * g].a, r[4 * g + 1].a, r[4 * g + 2].a, r[4 * g + 3].a));
+        gstore4(out.p[1] + i, make_uint4(r[4 * g].b, r[4 * g + 1].b, r[4 * g + 2].b, r[4 * g + 3].b));
+        gstore4(out.p[2] + i, make_uint4(r[4 * g].c, r[4 * g + 1].c, r[4 * g + 2].c, r[4 * g + 3].c));
+        gstore4(out.p[3] + i, make_uint4(r[4 * g].d, r[4 * g + 1].d, r[4 * g + 2].d, r[4 * g + 3].d));
     }
 }
 
@@ -223,15 +223,15 @@ int finish_inverse() {
 // ---------------------------------------------------------------- bit reverse (backend/cpu/index.ts:62-79)
 // In-place swap of i <-> bitrev(i) for i < bitrev(i); one column per blockIdx.y.
 __global__ void __launch_bounds__(256) k_bit_reverse(ColPtrs cols, u32 log_n) {
-    u32 *v = colp(cols, blockIdx.y);
+    u32 *v = colp_u(cols, blockIdx.y);
     size_t n = (size_t)1 << log_n;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         u32 j = __brev((u32)i) >> (32 - log_n);
         if (j > i) {
-            u32 a = v[i], b = v[j];
-            v[i] = b;
-            v[j] = a;
+            u32 a = gload1(v + i), b = gload1(v + j);
+            gstore1(v + i, b);
+            gstore1(v + j, a);
         }
     }
 }
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_bit_reverse(ColPtrs cols, u32 log_n) {
 __global__ void __launch_bounds__(256) k_bit_reverse_tiled(ColPtrs cols, u32 log_n) {
     constexpr int T = 6, S = 1 << T, STRIDE = S + 1;
     __shared__ u32 lds[2][S * STRIDE];
-    u32 *__restrict__ v = colp(cols, blockIdx.y);
+    u32 *__restrict__ v = colp_u(cols, blockIdx.y);
     const u32 mid_bits = log_n - 2 * T;
     const u32 m = blockIdx.x;
     const u32 rm = mid_bits ? (__brev(m) >> (32 - mid_bits)) : 0u;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) k_bit_reverse_tiled(ColPtrs cols, u32 log
         for (int it = 0; it < S * S / (256 * 4); it++) {
             const u32 idx4 = threadIdx.x + it * 256;
             const u32 a = idx4 / (S / 4), b4 = (idx4 % (S / 4)) * 4;
-            const uint4 x = *reinterpret_cast<const uint4 *>(v + (((size_t)a << row_shift) | ((size_t)mm << T) | b4));
+            const uint4 x = gload4(v + (((size_t)a << row_shift) | ((size_t)mm << T) | b4));
             u32 *p = &lds[which][a * STRIDE + b4];
             p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
         }
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_bit_reverse_tiled(ColPtrs cols, u32 log
             x.y = L[(__brev(c4 + 1) >> (32 - T)) * STRIDE + rr];
             x.z = L[(__brev(c4 + 2) >> (32 - T)) * STRIDE + rr];
             x.w = L[(__brev(c4 + 3) >> (32 - T)) * STRIDE + rr];
-            *reinterpret_cast<uint4 *>(v + (((size_t)r << row_shift) | ((size_t)dst << T) | c4)) = x;
+            gstore4(v + (((size_t)r << row_shift) | ((size_t)dst << T) | c4), x);
         }
     }
 }

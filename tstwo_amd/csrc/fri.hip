@@ -18,10 +18,10 @@ namespace {
 
 __device__ __forceinline__ qm31 load_pair_fold(const CSoa4 &in, size_t i, u32 t, qm31 *f0_out) {
     // (f0, f1) = ibutterfly(in[2i], in[2i+1], t) per coordinate (fft.ts:25-30)
-    uint2 a = *reinterpret_cast<const uint2 *>(in.p[0] + 2 * i);
-    uint2 b = *reinterpret_cast<const uint2 *>(in.p[1] + 2 * i);
-    uint2 c = *reinterpret_cast<const uint2 *>(in.p[2] + 2 * i);
-    uint2 d = *reinterpret_cast<const uint2 *>(in.p[3] + 2 * i);
+    uint2 a = gload2(in.p[0] + 2 * i);
+    uint2 b = gload2(in.p[1] + 2 * i);
+    uint2 c = gload2(in.p[2] + 2 * i);
+    uint2 d = gload2(in.p[3] + 2 * i);
     *f0_out = {m31_add(a.x, a.y), m31_add(b.x, b.y), m31_add(c.x, c.y), m31_add(d.x, d.y)};
     qm31 diff = {m31_sub(a.x, a.y), m31_sub(b.x, b.y), m31_sub(c.x, c.y), m31_sub(d.x, d.y)};
     return qm31_mul_m31(diff, t);
@@ -178,17 +178,17 @@ __global__ void __launch_bounds__(256) k_eval_coeffs(ColPtrs cols, size_t n_coef
                                                     size_t out_stride) {
     __shared__ qm31 tab[32 + 4];
     const u32 t = threadIdx.x;
-    const u32 *__restrict__ c = colp(cols, blockIdx.y);
+    const u32 *__restrict__ c = colp_u(cols, blockIdx.y);
     const size_t base = (size_t)blockIdx.x * (4096 * G) + 4 * t;
     auto load_group = [&](uint4 (&x)[4], int g) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const size_t i = base + 4096 * (size_t)g + 1024 * (size_t)r;
             if (FAST) {
-                x[r] = *reinterpret_cast<const uint4 *>(c + i);
+                x[r] = gload4(c + i);
             } else {
-                x[r].x = i + 0 < n_coeffs ? c[i + 0] : 0u; x[r].y = i + 1 < n_coeffs ? c[i + 1] : 0u;
-                x[r].z = i + 2 < n_coeffs ? c[i + 2] : 0u; x[r].w = i + 3 < n_coeffs ? c[i + 3] : 0u;
+                x[r].x = i + 0 < n_coeffs ? gload1(c + i + 0) : 0u; x[r].y = i + 1 < n_coeffs ? gload1(c + i + 1) : 0u;
+                x[r].z = i + 2 < n_coeffs ? gload1(c + i + 2) : 0u; x[r].w = i + 3 < n_coeffs ? gload1(c + i + 3) : 0u;
             }
         }
     };

@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
         for (u32 j = bc.begin; j < bc.end; j++) {
             const Entry en = entries[j];
             const u32 *col = cols[en.col];
-            uint4 f0 = *reinterpret_cast<const uint4 *>(col + row0);
-            uint4 f1 = *reinterpret_cast<const uint4 *>(col + row0 + 4);
+            uint4 f0 = gload4(col + row0);
+            uint4 f1 = gload4(col + row0 + 4);
             u32 f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
             for (int s = 0; s < 8; s++) num[s] = qm31_add(num[s], qm31_mul_m31(en.c, f[s]));
@@ -96,14 +96,14 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
         }
     }
     if (zero) atomicOr(flag, 1u);
-    *reinterpret_cast<uint4 *>(out.p[0] + row0) = make_uint4(acc[0].a, acc[1].a, acc[2].a, acc[3].a);
-    *reinterpret_cast<uint4 *>(out.p[0] + row0 + 4) = make_uint4(acc[4].a, acc[5].a, acc[6].a, acc[7].a);
-    *reinterpret_cast<uint4 *>(out.p[1] + row0) = make_uint4(acc[0].b, acc[1].b, acc[2].b, acc[3].b);
-    *reinterpret_cast<uint4 *>(out.p[1] + row0 + 4) = make_uint4(acc[4].b, acc[5].b, acc[6].b, acc[7].b);
-    *reinterpret_cast<uint4 *>(out.p[2] + row0) = make_uint4(acc[0].c, acc[1].c, acc[2].c, acc[3].c);
-    *reinterpret_cast<uint4 *>(out.p[2] + row0 + 4) = make_uint4(acc[4].c, acc[5].c, acc[6].c, acc[7].c);
-    *reinterpret_cast<uint4 *>(out.p[3] + row0) = make_uint4(acc[0].d, acc[1].d, acc[2].d, acc[3].d);
-    *reinterpret_cast<uint4 *>(out.p[3] + row0 + 4) = make_uint4(acc[4].d, acc[5].d, acc[6].d, acc[7].d);
+    gstore4(out.p[0] + row0, make_uint4(acc[0].a, acc[1].a, acc[2].a, acc[3].a));
+    gstore4(out.p[0] + row0 + 4, make_uint4(acc[4].a, acc[5].a, acc[6].a, acc[7].a));
+    gstore4(out.p[1] + row0, make_uint4(acc[0].b, acc[1].b, acc[2].b, acc[3].b));
+    gstore4(out.p[1] + row0 + 4, make_uint4(acc[4].b, acc[5].b, acc[6].b, acc[7].b));
+    gstore4(out.p[2] + row0, make_uint4(acc[0].c, acc[1].c, acc[2].c, acc[3].c));
+    gstore4(out.p[2] + row0 + 4, make_uint4(acc[4].c, acc[5].c, acc[6].c, acc[7].c));
+    gstore4(out.p[3] + row0, make_uint4(acc[0].d, acc[1].d, acc[2].d, acc[3].d));
+    gstore4(out.p[3] + row0 + 4, make_uint4(acc[4].d, acc[5].d, acc[6].d, acc[7].d));
 }
 
 // Any log_size (used for log_size < 3): one row per lane, the reference's formulation verbatim.
