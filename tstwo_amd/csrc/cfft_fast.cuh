@@ -32,62 +32,133 @@ __device__ __forceinline__ void bfly(u32 &a, u32 &b, u32 t2) {
     else bf_dbl(a, b, t2);
 }
 
-// G layers on LDS bits [Q, Q+G) of a 2^G-word register group; twiddles from the heap:
-// layer bit b lives at twl[2^(LOGT-1-b) + (e >> (b+1))].
-template <int G, int Q, int LOGT, bool INV>
-__device__ __forceinline__ void group_layers(u32 (&v)[1 << G], const u32 *twl, const u32 high) {
+// G layers on LDS bits [Q, Q+G) of NG register groups of 2^G words each (NG << G = 16 words per lane); twiddles from the
+// heap: layer bit b lives at twl[2^(LOGT-1-b) + (e >> (b+1))].  Every layer is ONE bf_layer of 8 butterflies (priority
+// phases: cfft.hip); returns at kPrioLight.
+template <int G, int NG, int Q, int LOGT, bool INV>
+__device__ __forceinline__ void groups_layers(u32 (&v)[NG][1 << G], const u32 *twl, const u32 (&high)[NG]) {
+    constexpr int HALF = 1 << (G - 1), N = NG * HALF;
 #pragma unroll
     for (int step = 0; step < G; step++) {
         const int l = INV ? step : (G - 1 - step);
-        const u32 *tl = twl + (1u << (LOGT - 1 - (Q + l))) + (high << (G - 1 - l));
+        u32 x[N], y[N], tw[N];
 #pragma unroll
-        for (int j = 0; j < (1 << (G - 1 - l)); j++) {
-            const u32 t2 = tl[j];
+        for (int g = 0; g < NG; g++) {
+            const u32 *tl = twl + (1u << (LOGT - 1 - (Q + l))) + (high[g] << (G - 1 - l));
 #pragma unroll
-            for (int r = 0; r < (1 << l); r++) {
-                const int m0 = (j << (l + 1)) | r;
-                bfly<INV>(v[m0], v[m0 + (1 << l)], t2);
+            for (int j = 0; j < (1 << (G - 1 - l)); j++) {
+                const u32 t2 = tl[j];
+#pragma unroll
+                for (int r = 0; r < (1 << l); r++) {
+                    const int m0 = (j << (l + 1)) | r, i = g * HALF + (j << l) + r;
+                    x[i] = v[g][m0]; y[i] = v[g][m0 + (1 << l)]; tw[i] = t2;
+                }
             }
         }
+        bf_layer<INV, N>(x, y, tw);
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int j = 0; j < (1 << (G - 1 - l)); j++)
+#pragma unroll
+                for (int r = 0; r < (1 << l); r++) {
+                    const int m0 = (j << (l + 1)) | r, i = g * HALF + (j << l) + r;
+                    v[g][m0] = x[i]; v[g][m0 + (1 << l)] = y[i];
+                }
     }
+    TSTWO_PHASE(kPrioLight);
 }
 
 // In-place LDS stage: every lane handles 16 >> G groups of 2^G words.
 template <int G, int Q, int LOGT, int THREADS, bool INV>
 __device__ __forceinline__ void lds_stage(u32 *lds, const u32 *twl) {
+    constexpr int NG = 16 >> G;
+    u32 v[NG][1 << G], high[NG];
+    u32 *p[NG];
 #pragma unroll
-    for (int g = 0; g < (16 >> G); g++) {
+    for (int g = 0; g < NG; g++) {
         u32 gid = threadIdx.x + (u32)g * THREADS;
         if (Q == 4) gid = (gid & ~0x30u) | ((gid & 0x10u) << 1) | ((gid & 0x20u) >> 1);   // bank-conflict-free lane -> group map
-        const u32 low = gid & ((1u << Q) - 1u), high = gid >> Q;
-        u32 *p = lds + pad((high << (Q + G)) | low);
-        u32 v[1 << G];
+        const u32 low = gid & ((1u << Q) - 1u);
+        high[g] = gid >> Q;
+        p[g] = lds + pad((high[g] << (Q + G)) | low);
 #pragma unroll
-        for (int m = 0; m < (1 << G); m++) v[m] = p[off<Q>(m)];
-        group_layers<G, Q, LOGT, INV>(v, twl, high);
-#pragma unroll
-        for (int m = 0; m < (1 << G); m++) p[off<Q>(m)] = v[m];
+        for (int m = 0; m < (1 << G); m++) v[g][m] = p[g][off<Q>(m)];
     }
+    groups_layers<G, NG, Q, LOGT, INV>(v, twl, high);
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int m = 0; m < (1 << G); m++) p[g][off<Q>(m)] = v[g][m];
 }
 
 // The pass's two top layers on the four quarter-tile vectors of a lane (component-wise radix-4).
 // x[j], j = (top bit, second bit).  ta: top-layer twiddle; tb0/tb1: second-layer twiddles of the two halves.
-template <bool INV, bool TWO>
-__device__ __forceinline__ void top_layers(uint4 (&x)[4], u32 ta, u32 tb0, u32 tb1) {
-    u32 *p0 = reinterpret_cast<u32 *>(&x[0]), *p1 = reinterpret_cast<u32 *>(&x[1]);
-    u32 *p2 = reinterpret_cast<u32 *>(&x[2]), *p3 = reinterpret_cast<u32 *>(&x[3]);
+// (a, c), (b, d) with ta — the pass's top layer; leaves the wave at kPrioHeavy like bf_layer
+template <bool INV>
+__device__ __forceinline__ void quarter_layer_top(uint4 (&q)[4], u32 ta) {
+    u32 *p0 = reinterpret_cast<u32 *>(&q[0]), *p1 = reinterpret_cast<u32 *>(&q[1]);
+    u32 *p2 = reinterpret_cast<u32 *>(&q[2]), *p3 = reinterpret_cast<u32 *>(&q[3]);
+    u32 x[8], y[8], tw[8];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        u32 a = p0[k], b = p1[k], c = p2[k], d = p3[k];
-        if (!INV) {
-            bfly<false>(a, c, ta); bfly<false>(b, d, ta);
-            if (TWO) { bfly<false>(a, b, tb0); bfly<false>(c, d, tb1); }
-        } else {
-            if (TWO) { bfly<true>(a, b, tb0); bfly<true>(c, d, tb1); }
-            bfly<true>(a, c, ta); bfly<true>(b, d, ta);
-        }
-        p0[k] = a; p1[k] = b; p2[k] = c; p3[k] = d;
+    for (int k = 0; k < 4; k++) { x[k] = p0[k]; y[k] = p2[k]; x[4 + k] = p1[k]; y[4 + k] = p3[k]; tw[k] = ta; tw[4 + k] = ta; }
+    bf_layer<INV, 8>(x, y, tw);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p0[k] = x[k]; p2[k] = y[k]; p1[k] = x[4 + k]; p3[k] = y[4 + k]; }
+}
+// (a, b) with tb0, (c, d) with tb1 — the second layer
+template <bool INV>
+__device__ __forceinline__ void quarter_layer_second(uint4 (&q)[4], u32 tb0, u32 tb1) {
+    u32 *p0 = reinterpret_cast<u32 *>(&q[0]), *p1 = reinterpret_cast<u32 *>(&q[1]);
+    u32 *p2 = reinterpret_cast<u32 *>(&q[2]), *p3 = reinterpret_cast<u32 *>(&q[3]);
+    u32 x[8], y[8], tw[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[k] = p0[k]; y[k] = p1[k]; x[4 + k] = p2[k]; y[4 + k] = p3[k]; tw[k] = tb0; tw[4 + k] = tb1; }
+    bf_layer<INV, 8>(x, y, tw);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { p0[k] = x[k]; p1[k] = y[k]; p2[k] = x[4 + k]; p3[k] = y[4 + k]; }
+}
+template <bool INV, bool TWO>
+__device__ __forceinline__ void top_layers(uint4 (&q)[4], u32 ta, u32 tb0, u32 tb1) {
+    if (!INV) {
+        quarter_layer_top<false>(q, ta);
+        if (TWO) quarter_layer_second<false>(q, tb0, tb1);
+    } else {
+        if (TWO) quarter_layer_second<true>(q, tb0, tb1);
+        quarter_layer_top<true>(q, ta);
     }
+    TSTWO_PHASE(kPrioLight);
+}
+
+// The four lowest layers of the bottom pass on a lane's 16 consecutive words: layer 3 (t3), layer 2 (t2[2]), layer 1
+// (t1[4]) and the circle layer (t1 again, permuted and negated: backend/cpu/circle.ts:153-185), 8 butterflies each.
+template <bool INV>
+__device__ __forceinline__ void low_layers(u32 (&v)[16], const u32 (&t1)[4], const u32 (&t2)[2], u32 t3) {
+    u32 tc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        tc[j] = t1[(j >> 1) ^ 1];
+        if ((j ^ (j >> 1)) & 1) tc[j] = 0xFFFFFFFEu - tc[j];
+    }
+#pragma unroll
+    for (int step = 0; step < 4; step++) {
+        const int layer = INV ? step : 3 - step;          // 0 = circle layer
+        const int l = layer;                              // partner distance 2^l (circle layer: adjacent words)
+        u32 x[8], y[8], tw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = ((i >> l) << (l + 1)) | (i & ((1 << l) - 1));       // the i-th word with bit l clear
+            x[i] = v[m]; y[i] = v[m + (1 << l)];
+            tw[i] = layer == 0 ? tc[m >> 1] : layer == 1 ? t1[m >> 2] : layer == 2 ? t2[m >> 3] : t3;
+        }
+        bf_layer<INV, 8>(x, y, tw);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = ((i >> l) << (l + 1)) | (i & ((1 << l) - 1));
+            v[m] = x[i]; v[m + (1 << l)] = y[i];
+        }
+    }
+    TSTWO_PHASE(kPrioLight);
 }
 
 __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
@@ -181,18 +252,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             u32 v[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) v[m] = lds[pad(16 * t) + m];
-#pragma unroll
-            for (int m = 0; m < 8; m++) bf_dbl(v[m], v[m + 8], t3);                                  // layer 3
-#pragma unroll
-            for (int m = 0; m < 16; m++) if (!(m & 4)) bf_dbl(v[m], v[m + 4], t2[m >> 3]);           // layer 2
-#pragma unroll
-            for (int m = 0; m < 16; m++) if (!(m & 2)) bf_dbl(v[m], v[m + 2], t1[m >> 2]);           // layer 1
-#pragma unroll
-            for (int j = 0; j < 8; j++) {                                                            // circle layer
-                u32 tc = t1[(j >> 1) ^ 1];
-                if ((j ^ (j >> 1)) & 1) tc = 0xFFFFFFFEu - tc;
-                bf_dbl(v[2 * j], v[2 * j + 1], tc);
-            }
+            low_layers<false>(v, t1, t2, t3);                              // layers 3, 2, 1 and the circle layer
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #ifdef TSTWO_EXP_B_STORE
@@ -205,18 +265,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             u32 v[16];
 #pragma unroll
             for (int j = 0; j < 4; j++) { v[4 * j] = pf[j].x; v[4 * j + 1] = pf[j].y; v[4 * j + 2] = pf[j].z; v[4 * j + 3] = pf[j].w; }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                u32 tc = t1[(j >> 1) ^ 1];
-                if ((j ^ (j >> 1)) & 1) tc = 0xFFFFFFFEu - tc;
-                ibf_dbl(v[2 * j], v[2 * j + 1], tc);
-            }
-#pragma unroll
-            for (int m = 0; m < 16; m++) if (!(m & 2)) ibf_dbl(v[m], v[m + 2], t1[m >> 2]);
-#pragma unroll
-            for (int m = 0; m < 16; m++) if (!(m & 4)) ibf_dbl(v[m], v[m + 4], t2[m >> 3]);
-#pragma unroll
-            for (int m = 0; m < 8; m++) ibf_dbl(v[m], v[m + 8], t3);
+            low_layers<true>(v, t1, t2, t3);
 #pragma unroll
             for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
             lds_barrier();
@@ -346,10 +395,8 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
                 top_layers<INV, F == 2>(pf, ta, tb0, tb1);
             } else if constexpr (EXT == 1) {     // top layer replicates: x2 = x0, x3 = x1; second layer is real
                 pf[2] = pf[0]; pf[3] = pf[1];
-                u32 *p0 = reinterpret_cast<u32 *>(&pf[0]), *p1 = reinterpret_cast<u32 *>(&pf[1]);
-                u32 *p2 = reinterpret_cast<u32 *>(&pf[2]), *p3 = reinterpret_cast<u32 *>(&pf[3]);
-#pragma unroll
-                for (int k = 0; k < 4; k++) { bfly<false>(p0[k], p1[k], tb0); bfly<false>(p2[k], p3[k], tb1); }
+                quarter_layer_second<false>(pf, tb0, tb1);
+                TSTWO_PHASE(kPrioLight);
             } else {                              // both register layers replicate
                 pf[1] = pf[0]; pf[2] = pf[0]; pf[3] = pf[0];
             }
@@ -374,21 +421,20 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
                     lds_barrier();
                 }
                 // final stage: butterflies, then straight to HBM (rows of 2^C words: >= 128 B per half-wave)
+                {
+                    constexpr int NG = 16 >> G2;
+                    u32 v[NG][1 << G2], high[NG];
 #pragma unroll
-                for (int g = 0; g < (16 >> G2); g++) {
-                    const u32 high = (t + (u32)g * THREADS) >> C;
-                    u32 v[1 << G2];
+                    for (int g = 0; g < NG; g++) {
+                        high[g] = (t + (u32)g * THREADS) >> C;
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) v[m] = lds[pad(e_final(tt, g, 0)) + off<C>(m)];
-                    group_layers<G2, C, LOGT, false>(v, twl, high);
-#ifdef TSTWO_EXP_A_STORE
+                        for (int m = 0; m < (1 << G2); m++) v[g][m] = lds[pad(e_final(tt, g, 0)) + off<C>(m)];
+                    }
+                    groups_layers<G2, NG, C, LOGT, false>(v, twl, high);
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m += 4)
-                        *reinterpret_cast<uint4 *>(data + goff(4 * t + ((g * (1 << G2) + m) / 4) * QT)) = make_uint4(v[m], v[m + 1], v[m + 2], v[m + 3]);
-#else
+                    for (int g = 0; g < NG; g++)
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) gstore1(data + goff(e_final(tt, g, m)), v[m]);
-#endif
+                        for (int m = 0; m < (1 << G2); m++) gstore1(data + goff(e_final(tt, g, m)), v[g][m]);
                 }
                 lds_barrier();
             }
@@ -411,15 +457,20 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
             const u32 *__restrict__ next = colp_u(cols, min(col + 1, col1 - 1)) + base;
             u32 tt = t;
             asm volatile("" : "+v"(tt));
+            {
+                constexpr int NG = 16 >> G2;
+                u32 v[NG][1 << G2], high[NG];
 #pragma unroll
-            for (int g = 0; g < (16 >> G2); g++) {
-                const u32 high = (t + (u32)g * THREADS) >> C;
-                u32 v[1 << G2];
+                for (int g = 0; g < NG; g++) {
+                    high[g] = (t + (u32)g * THREADS) >> C;
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) v[m] = pfs[g * (1 << G2) + m];
-                group_layers<G2, C, LOGT, true>(v, twl, high);
+                    for (int m = 0; m < (1 << G2); m++) v[g][m] = pfs[g * (1 << G2) + m];
+                }
+                groups_layers<G2, NG, C, LOGT, true>(v, twl, high);
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(tt, g, 0)) + off<C>(m)] = v[m];
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(tt, g, 0)) + off<C>(m)] = v[g][m];
             }
             lds_barrier();
 #pragma unroll
