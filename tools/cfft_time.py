@@ -17,6 +17,7 @@ ap.add_argument("--cols", type=int, default=32)
 ap.add_argument("--log", type=int, default=22)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--inv", action="store_true")
+ap.add_argument("--series", type=int, default=0, help="also print the mean of every SERIES consecutive repetitions (clock behaviour over time)")
 a = ap.parse_args()
 L.init(0)
 n, N = a.log, 1 << a.log
@@ -35,6 +36,7 @@ t = itw if a.inv else tw
 for _ in range(3):
     L.call(name, ptrs, a.cols, n, half, C.c_void_p(t.ptr), n - 1)
 best, tot = 1e9, 0.0
+series = []
 for _ in range(a.reps):
     e0, e1 = L.Event(), L.Event()
     e0.record()
@@ -42,4 +44,7 @@ for _ in range(a.reps):
     e1.record()
     ms = e0.elapsed_ms(e1)
     best, tot = min(best, ms), tot + ms
+    series.append(ms)
 print(f"{os.environ.get('TSTWO_HIP_LIB', 'default')} {name} {a.cols} x 2^{n}: avg {tot / a.reps * 1e3:.1f} us  min {best * 1e3:.1f} us", flush=True)
+if a.series:
+    print("  series (us):", " ".join(f"{sum(series[i:i + a.series]) / len(series[i:i + a.series]) * 1e3:.0f}" for i in range(0, len(series), a.series)), flush=True)

@@ -157,7 +157,7 @@ static float time_kernel(kern_t k, int blocks, u32 *out) {
     }
     return best;
 }
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
@@ -174,6 +174,24 @@ int main() {
                   {"add not in place, shared src1", k_add_notinplace}, {"add two fresh sources", k_add_two_fresh}, {"add ring (a_i += a_i+4)", k_add_ring}};
     for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_add, dim3(cus * 8), dim3(256), 0, 0, out, 1u);
     hipDeviceSynchronize();
+    if (argc > 1) {      // sustained run: the same kernel back to back for ~1.5 s, rate per 50 launches (clock behaviour under load)
+        kern_t k = argv[1][0] == 'b' ? k_bf_prio : argv[1][0] == 'p' ? k_bf_plain : argv[1][0] == 'k' ? k_blake_run_prio : k_add;
+        const double n = (argv[1][0] == 'b' || argv[1][0] == 'p') ? 264 : 64;
+        printf("sustained %s: nominal cycles per instruction, 8 waves/SIMD, per 50 launches:", argv[1]);
+        for (int round = 0; round < 40; round++) {
+            hipEvent_t a, b;
+            hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a);
+            for (int i = 0; i < 50; i++) hipLaunchKernelGGL(k, dim3(cus * 8), dim3(256), 0, 0, out, 3u);
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            float ms = 0;
+            hipEventElapsedTime(&ms, a, b);
+            printf(" %.2f", ms / 50 * 1e-3 * clk / ((double)ITERS * n * 8));
+        }
+        printf("\n");
+        return 0;
+    }
     printf("{\"note\": \"cycles per wave64 instruction (nominal %.0f MHz) at 1/2/4/8 waves per SIMD; 64 instructions per loop iteration\",\n", clk / 1e6);
     const int n = sizeof(es) / sizeof(es[0]);
     for (int e = 0; e < n; e++) {

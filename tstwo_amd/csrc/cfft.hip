@@ -72,57 +72,48 @@ __device__ __forceinline__ void ibf_dbl(u32 &v0, u32 &v1, u32 t2) {
     v0 = a;
 }
 
-// ---- butterflies in priority phases (the tiled kernels' form; DESIGN.md 4.1, tools/microbench3.hip, microbench4.hip).
-// Each SIMD has two VALU issue ports.  Port 0 takes the next instruction of the highest-priority (then oldest) ready wave,
-// whatever it is; port 1 takes, in the same ~4.4-cycle slot, a "light" VOP2 of ANOTHER wave — v_add/v_sub/v_xor/v_and/
-// v_lshrrev/v_mov with VGPR or inline-constant operands (no literal, no SGPR).  v_min, v_mad_u64_u32, every VOP3 are
-// "heavy": port 0 only.  With equal priorities the oldest wave owns port 0 and every other wave stalls at its first heavy
-// instruction, so a mixed stream issues one instruction per slot (the 44-cycle butterfly of round 1).  Here a layer's N
-// butterflies are issued opcode by opcode, and the wave raises its priority for the heavy runs: heavy runs queue for port 0,
-// light runs of the other waves fill port 1.  Measured on the same 11 instructions: 2.6 instead of 4.1 cycles each.
-// The modulus sits in a VGPR for that reason (a literal operand makes v_add / v_sub heavy).
+// ---- butterflies in priority phases (the issue model and TSTWO_PHASE: common.h)
+// The modulus sits in a VGPR: a literal operand makes v_add / v_sub heavy.
 __device__ __forceinline__ u32 vgpr_P() {
     u32 p = M31_P;
     asm("" : "+v"(p));
     return p;
 }
-// nothing but LDS / global memory instructions may be scheduled across a phase boundary
-#define TSTWO_PHASE(prio) do { __builtin_amdgcn_sched_barrier(0x90); __builtin_amdgcn_s_setprio(prio); __builtin_amdgcn_sched_barrier(0x90); } while (0)
-constexpr int kPrioHeavy = 3, kPrioLight = 0;
 // N independent butterflies (x[i], y[i]) with doubled twiddles t2[i]; leaves the wave at kPrioHeavy (the next layer starts
 // heavy as well) — the caller drops to kPrioLight after its last layer.
 template <bool INV, int N>
 __device__ __forceinline__ void bf_layer(u32 (&x)[N], u32 (&y)[N], const u32 (&t2)[N]) {
+    static_assert(N == 8, "phase() pins 8 or 16 values");
     const u32 P = vgpr_P();
     u32 s[N], d[N], u[N], w[N], u2[N], w2[N];
     u64 p[N];
     if (!INV) {
-        TSTWO_PHASE(kPrioHeavy);
+        phase<kPrioHeavy>(y);
 #pragma unroll
         for (int i = 0; i < N; i++) p[i] = (u64)y[i] * (u64)t2[i];
-        TSTWO_PHASE(kPrioLight);
+        phase<kPrioLight>(p);
 #pragma unroll
         for (int i = 0; i < N; i++) { s[i] = (u32)(p[i] >> 32) + ((u32)p[i] >> 1); d[i] = s[i] - P; }
-        TSTWO_PHASE(kPrioHeavy);
+        phase<kPrioHeavy>(d);
 #pragma unroll
         for (int i = 0; i < N; i++) s[i] = min(s[i], d[i]);
-        TSTWO_PHASE(kPrioLight);
+        phase<kPrioLight>(s);
 #pragma unroll
         for (int i = 0; i < N; i++) { u[i] = x[i] + s[i]; w[i] = x[i] - s[i]; u2[i] = u[i] - P; w2[i] = w[i] + P; }
-        TSTWO_PHASE(kPrioHeavy);
+        phase<kPrioHeavy>(u2, w2);
 #pragma unroll
         for (int i = 0; i < N; i++) { x[i] = min(u[i], u2[i]); y[i] = min(w[i], w2[i]); }
     } else {
-        TSTWO_PHASE(kPrioLight);
+        phase<kPrioLight>(x, y);
 #pragma unroll
         for (int i = 0; i < N; i++) { u[i] = x[i] + y[i]; w[i] = x[i] - y[i]; u2[i] = u[i] - P; w2[i] = w[i] + P; }
-        TSTWO_PHASE(kPrioHeavy);
+        phase<kPrioHeavy>(u2, w2);
 #pragma unroll
         for (int i = 0; i < N; i++) { x[i] = min(u[i], u2[i]); p[i] = (u64)min(w[i], w2[i]) * (u64)t2[i]; }
-        TSTWO_PHASE(kPrioLight);
+        phase<kPrioLight>(p);
 #pragma unroll
         for (int i = 0; i < N; i++) { s[i] = (u32)(p[i] >> 32) + ((u32)p[i] >> 1); d[i] = s[i] - P; }
-        TSTWO_PHASE(kPrioHeavy);
+        phase<kPrioHeavy>(d);
 #pragma unroll
         for (int i = 0; i < N; i++) y[i] = min(s[i], d[i]);
     }
@@ -132,6 +123,9 @@ __device__ __forceinline__ void bf_layer(u32 (&x)[N], u32 (&y)[N], const u32 (&t
 // serialise the in-flight prefetch loads / tile stores behind every stage (guide §5 "Pipelining across
 // barriers"); global memory is never shared between lanes inside these kernels, so LDS ordering suffices.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Ordering between LDS accesses of ONE wave (a stage whose exchange stays inside the wave): the LDS executes a wave's
+// instructions in issue order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void lds_wave_fence() { asm volatile("" ::: "memory"); }
 
 }  // namespace
 #include "cfft_fast.cuh"

@@ -56,6 +56,7 @@ __device__ __forceinline__ void groups_layers(u32 (&v)[NG][1 << G], const u32 *t
             }
         }
         bf_layer<INV, N>(x, y, tw);
+        if (step == G - 1) phase<kPrioLight>(x, y);
 #pragma unroll
         for (int g = 0; g < NG; g++)
 #pragma unroll
@@ -66,7 +67,6 @@ __device__ __forceinline__ void groups_layers(u32 (&v)[NG][1 << G], const u32 *t
                     v[g][m0] = x[i]; v[g][m0 + (1 << l)] = y[i];
                 }
     }
-    TSTWO_PHASE(kPrioLight);
 }
 
 // In-place LDS stage: every lane handles 16 >> G groups of 2^G words.
@@ -94,8 +94,8 @@ __device__ __forceinline__ void lds_stage(u32 *lds, const u32 *twl) {
 
 // The pass's two top layers on the four quarter-tile vectors of a lane (component-wise radix-4).
 // x[j], j = (top bit, second bit).  ta: top-layer twiddle; tb0/tb1: second-layer twiddles of the two halves.
-// (a, c), (b, d) with ta — the pass's top layer; leaves the wave at kPrioHeavy like bf_layer
-template <bool INV>
+// (a, c), (b, d) with ta — the pass's top layer; leaves the wave at kPrioHeavy like bf_layer unless LAST
+template <bool INV, bool LAST>
 __device__ __forceinline__ void quarter_layer_top(uint4 (&q)[4], u32 ta) {
     u32 *p0 = reinterpret_cast<u32 *>(&q[0]), *p1 = reinterpret_cast<u32 *>(&q[1]);
     u32 *p2 = reinterpret_cast<u32 *>(&q[2]), *p3 = reinterpret_cast<u32 *>(&q[3]);
@@ -103,11 +103,12 @@ __device__ __forceinline__ void quarter_layer_top(uint4 (&q)[4], u32 ta) {
 #pragma unroll
     for (int k = 0; k < 4; k++) { x[k] = p0[k]; y[k] = p2[k]; x[4 + k] = p1[k]; y[4 + k] = p3[k]; tw[k] = ta; tw[4 + k] = ta; }
     bf_layer<INV, 8>(x, y, tw);
+    if (LAST) phase<kPrioLight>(x, y);
 #pragma unroll
     for (int k = 0; k < 4; k++) { p0[k] = x[k]; p2[k] = y[k]; p1[k] = x[4 + k]; p3[k] = y[4 + k]; }
 }
 // (a, b) with tb0, (c, d) with tb1 — the second layer
-template <bool INV>
+template <bool INV, bool LAST>
 __device__ __forceinline__ void quarter_layer_second(uint4 (&q)[4], u32 tb0, u32 tb1) {
     u32 *p0 = reinterpret_cast<u32 *>(&q[0]), *p1 = reinterpret_cast<u32 *>(&q[1]);
     u32 *p2 = reinterpret_cast<u32 *>(&q[2]), *p3 = reinterpret_cast<u32 *>(&q[3]);
@@ -115,19 +116,19 @@ __device__ __forceinline__ void quarter_layer_second(uint4 (&q)[4], u32 tb0, u32
 #pragma unroll
     for (int k = 0; k < 4; k++) { x[k] = p0[k]; y[k] = p1[k]; x[4 + k] = p2[k]; y[4 + k] = p3[k]; tw[k] = tb0; tw[4 + k] = tb1; }
     bf_layer<INV, 8>(x, y, tw);
+    if (LAST) phase<kPrioLight>(x, y);
 #pragma unroll
     for (int k = 0; k < 4; k++) { p0[k] = x[k]; p1[k] = y[k]; p2[k] = x[4 + k]; p3[k] = y[4 + k]; }
 }
 template <bool INV, bool TWO>
 __device__ __forceinline__ void top_layers(uint4 (&q)[4], u32 ta, u32 tb0, u32 tb1) {
     if (!INV) {
-        quarter_layer_top<false>(q, ta);
-        if (TWO) quarter_layer_second<false>(q, tb0, tb1);
+        quarter_layer_top<false, !TWO>(q, ta);
+        if (TWO) quarter_layer_second<false, true>(q, tb0, tb1);
     } else {
-        if (TWO) quarter_layer_second<true>(q, tb0, tb1);
-        quarter_layer_top<true>(q, ta);
+        if (TWO) quarter_layer_second<true, false>(q, tb0, tb1);
+        quarter_layer_top<true, true>(q, ta);
     }
-    TSTWO_PHASE(kPrioLight);
 }
 
 // The four lowest layers of the bottom pass on a lane's 16 consecutive words: layer 3 (t3), layer 2 (t2[2]), layer 1
@@ -152,13 +153,13 @@ __device__ __forceinline__ void low_layers(u32 (&v)[16], const u32 (&t1)[4], con
             tw[i] = layer == 0 ? tc[m >> 1] : layer == 1 ? t1[m >> 2] : layer == 2 ? t2[m >> 3] : t3;
         }
         bf_layer<INV, 8>(x, y, tw);
+        if (step == 3) phase<kPrioLight>(x, y);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int m = ((i >> l) << (l + 1)) | (i & ((1 << l) - 1));
             v[m] = x[i]; v[m + (1 << l)] = y[i];
         }
     }
-    TSTWO_PHASE(kPrioLight);
 }
 
 __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
@@ -231,6 +232,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
         if (t >= 4) twl[t] = hv + hv;
         ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
     }
+    if (INV) lds_barrier();      // the inverse reads the heap in its first LDS stage, which no workgroup barrier precedes
 
     for (u32 col = col0; col < col1; col++) {
         u32 *__restrict__ data = colp_u(cols, col) + base;
@@ -248,10 +250,11 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             lds_stage<GM, 8, LOGT, THREADS, false>(lds, twl);              // layers LOGT-3..8
             lds_barrier();
             lds_stage<4, 4, LOGT, THREADS, false>(lds, twl);               // layers 7..4
-            lds_barrier();
+            lds_wave_fence();    // the 256-word blocks a wave wrote in that stage are the ones it reads now: no workgroup barrier
             u32 v[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) v[m] = lds[pad(16 * t) + m];
+            lds_barrier();       // last LDS access of this column: the next column's tile may overwrite it (the low layers run un-synchronised)
             low_layers<false>(v, t1, t2, t3);                              // layers 3, 2, 1 and the circle layer
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -260,7 +263,6 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
 #else
                 gstore4(data + 16 * t + 4 * j, make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
 #endif
-            lds_barrier();
         } else {
             u32 v[16];
 #pragma unroll
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             low_layers<true>(v, t1, t2, t3);
 #pragma unroll
             for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
-            lds_barrier();
+            lds_wave_fence();    // the next stage reads the blocks this wave has just written
 #pragma unroll
             for (int j = 0; j < 4; j++) pf[j] = gload4(next + 16 * t + 4 * j);
             lds_stage<4, 4, LOGT, THREADS, true>(lds, twl);
@@ -281,13 +283,13 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
                 const u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
                 x[j] = make_uint4(p[0], p[1], p[2], p[3]);
             }
+            lds_barrier();       // last LDS access of this column (see the forward branch)
             top_layers<true, true>(x, ta, tb0, tb1);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (scale) x[j] = scale4(x[j], scale);
                 gstore4(data + 4 * t + j * QT, x[j]);
             }
-            lds_barrier();
         }
     }
     }   // runs of one tile
@@ -395,8 +397,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
                 top_layers<INV, F == 2>(pf, ta, tb0, tb1);
             } else if constexpr (EXT == 1) {     // top layer replicates: x2 = x0, x3 = x1; second layer is real
                 pf[2] = pf[0]; pf[3] = pf[1];
-                quarter_layer_second<false>(pf, tb0, tb1);
-                TSTWO_PHASE(kPrioLight);
+                quarter_layer_second<false, true>(pf, tb0, tb1);
             } else {                              // both register layers replicate
                 pf[1] = pf[0]; pf[2] = pf[0]; pf[3] = pf[0];
             }
@@ -430,15 +431,16 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
 #pragma unroll
                         for (int m = 0; m < (1 << G2); m++) v[g][m] = lds[pad(e_final(tt, g, 0)) + off<C>(m)];
                     }
+                    lds_barrier();   // last access to the tile in LDS: the next column may overwrite it while this stage computes
                     groups_layers<G2, NG, C, LOGT, false>(v, twl, high);
 #pragma unroll
                     for (int g = 0; g < NG; g++)
 #pragma unroll
                         for (int m = 0; m < (1 << G2); m++) gstore1(data + goff(e_final(tt, g, m)), v[g][m]);
                 }
-                lds_barrier();
             }
         }
+        if constexpr (R > 0) lds_barrier();      // the final stage read the twiddle heap: the next run restages it
     } else {
         // inverse with LDS stages: the lane's 16 words arrive in the first-stage layout
         u32 pfs[16];
@@ -487,13 +489,13 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
                 const u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
                 x[j] = make_uint4(p[0], p[1], p[2], p[3]);
             }
+            lds_barrier();       // last LDS access of this column
             top_layers<true, F == 2>(x, ta, tb0, tb1);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (scale) x[j] = scale4(x[j], scale);
                 gstore4(data + goff(4 * t + j * QT), x[j]);
             }
-            lds_barrier();
         }
     }
     }   // runs of one tile

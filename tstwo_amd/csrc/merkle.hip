@@ -32,16 +32,45 @@ __device__ __forceinline__ u32 rotr32(u32 x, int r) { return __builtin_amdgcn_al
         c = c + d;       b = rotr32(b ^ c, 7);      \
     } while (0)
 
+// Four independent G functions (a column step or a diagonal step of a round) issued opcode by opcode in priority phases
+// (common.h: heavy = v_add3 / v_alignbit on port 0 at high priority, light = v_xor / v_add on either port): per step
+// 24 heavy + 24 light instructions.  Entered and left at kPrioHeavy.
+#define B2S_4(OP) OP(0) OP(1) OP(2) OP(3)
+#define B2S_STEP4(a0, b0, c0, d0, a1, b1, c1, d1, a2, b2, c2, d2, a3, b3, c3, d3, x0, y0, x1, y1, x2, y2, x3, y3) \
+    do {                                                                                                          \
+        a0 = a0 + b0 + (x0); a1 = a1 + b1 + (x1); a2 = a2 + b2 + (x2); a3 = a3 + b3 + (x3);                       \
+        phase<kPrioLight>(a0, a1, a2, a3);                                                                        \
+        d0 ^= a0; d1 ^= a1; d2 ^= a2; d3 ^= a3;                                                                   \
+        phase<kPrioHeavy>(d0, d1, d2, d3);                                                                        \
+        d0 = rotr32(d0, 16); d1 = rotr32(d1, 16); d2 = rotr32(d2, 16); d3 = rotr32(d3, 16);                       \
+        phase<kPrioLight>(d0, d1, d2, d3);                                                                        \
+        c0 += d0; c1 += d1; c2 += d2; c3 += d3;                                                                   \
+        b0 ^= c0; b1 ^= c1; b2 ^= c2; b3 ^= c3;                                                                   \
+        phase<kPrioHeavy>(b0, b1, b2, b3);                                                                        \
+        b0 = rotr32(b0, 12); b1 = rotr32(b1, 12); b2 = rotr32(b2, 12); b3 = rotr32(b3, 12);                       \
+        a0 = a0 + b0 + (y0); a1 = a1 + b1 + (y1); a2 = a2 + b2 + (y2); a3 = a3 + b3 + (y3);                       \
+        phase<kPrioLight>(a0, a1, a2, a3);                                                                        \
+        d0 ^= a0; d1 ^= a1; d2 ^= a2; d3 ^= a3;                                                                   \
+        phase<kPrioHeavy>(d0, d1, d2, d3);                                                                        \
+        d0 = rotr32(d0, 8); d1 = rotr32(d1, 8); d2 = rotr32(d2, 8); d3 = rotr32(d3, 8);                           \
+        phase<kPrioLight>(d0, d1, d2, d3);                                                                        \
+        c0 += d0; c1 += d1; c2 += d2; c3 += d3;                                                                   \
+        b0 ^= c0; b1 ^= c1; b2 ^= c2; b3 ^= c3;                                                                   \
+        phase<kPrioHeavy>(b0, b1, b2, b3);                                                                        \
+        b0 = rotr32(b0, 7); b1 = rotr32(b1, 7); b2 = rotr32(b2, 7); b3 = rotr32(b3, 7);                           \
+    } while (0)
+
 // One compression (vcs/blake2s_ref.ts:176-230): h <- F(h, m, t, last)
 __device__ __forceinline__ void b2s_compress(u32 h[8], const u32 m[16], u32 t_lo, bool last) {
     u32 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
     u32 v8 = IV0, v9 = IV1, v10 = IV2, v11 = IV3, v12 = IV4 ^ t_lo, v13 = IV5, v14 = last ? ~IV6 : IV6, v15 = IV7;
+    phase<kPrioHeavy>(v0, v1, v2, v3);
     // message schedule SIGMA (vcs/blake2s_ref.ts:9-20) written out so every m[] index is a literal
-#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
-    B2S_G(v0, v4, v8, v12, m[s0], m[s1]);   B2S_G(v1, v5, v9, v13, m[s2], m[s3]);       \
-    B2S_G(v2, v6, v10, v14, m[s4], m[s5]);  B2S_G(v3, v7, v11, v15, m[s6], m[s7]);      \
-    B2S_G(v0, v5, v10, v15, m[s8], m[s9]);  B2S_G(v1, v6, v11, v12, m[s10], m[s11]);    \
-    B2S_G(v2, v7, v8, v13, m[s12], m[s13]); B2S_G(v3, v4, v9, v14, m[s14], m[s15]);
+#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                                    \
+    B2S_STEP4(v0, v4, v8, v12, v1, v5, v9, v13, v2, v6, v10, v14, v3, v7, v11, v15,                                         \
+              m[s0], m[s1], m[s2], m[s3], m[s4], m[s5], m[s6], m[s7]);                                                      \
+    B2S_STEP4(v0, v5, v10, v15, v1, v6, v11, v12, v2, v7, v8, v13, v3, v4, v9, v14,                                         \
+              m[s8], m[s9], m[s10], m[s11], m[s12], m[s13], m[s14], m[s15]);
     B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
     B2S_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
     B2S_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
@@ -53,6 +82,7 @@ __device__ __forceinline__ void b2s_compress(u32 h[8], const u32 m[16], u32 t_lo
     B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
     B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
 #undef B2S_ROUND
+    phase<kPrioLight>(v4, v5, v6, v7);
     h[0] ^= v0 ^ v8;  h[1] ^= v1 ^ v9;  h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
     h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
