@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
     // waited for each one in turn (five round trips, ~5 us per launch of a few-column transform).
     uint4 pf[4];
     u32 t1[4], t2[2], t3, ta, tb0, tb1;
+    // word offset of the lane's 16-byte piece in its wave's 1024 consecutive words (x 4 pieces 256 words apart): the
+    // coalesced form of the lane's 16 consecutive words 16t .. 16t+15 (forward pass: final stores)
+    const u32 e0w = ((t >> 6) << 10) + 4 * (t & 63);
     {
         const u32 *__restrict__ d = src_of(col0);
 #pragma unroll
@@ -254,17 +257,28 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             u32 v[16];
 #pragma unroll
             for (int m = 0; m < 16; m++) v[m] = lds[pad(16 * t) + m];
-            lds_barrier();       // last LDS access of this column: the next column's tile may overwrite it (the low layers run un-synchronised)
             low_layers<false>(v, t1, t2, t3);                              // layers 3, 2, 1 and the circle layer
+            // The lane now holds 16 consecutive words (64 bytes): stored as they are, every store instruction would touch 64
+            // separate 64-byte segments a quarter each.  One more trip through the wave's own 1024 words of LDS turns them
+            // into four 1 KiB-contiguous 16-byte-per-lane stores (wave-local: no workgroup barrier).
+            lds_wave_fence();
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-#ifdef TSTWO_EXP_B_STORE
-                gstore4(data + 4 * t + j * QT, make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
-#else
-                gstore4(data + 16 * t + 4 * j, make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]));
-#endif
+            for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
+            lds_wave_fence();
+            const u32 e0 = e0w;
+            uint4 o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 *p = lds + pad(e0 + 256 * j);
+                o[j] = make_uint4(p[0], p[1], p[2], p[3]);
+            }
+            lds_barrier();       // last LDS access of this column: the next column's tile may overwrite it
+#pragma unroll
+            for (int j = 0; j < 4; j++) gstore4(data + e0 + 256 * j, o[j]);
         } else {
             u32 v[16];
+            // (the lane's 64 consecutive bytes arrive as four 16-byte loads; the coalesced form with a wave-local LDS exchange,
+            // which pays on the forward pass's store side, measured 2 % slower here: loads share their lines through the cache)
 #pragma unroll
             for (int j = 0; j < 4; j++) { v[4 * j] = pf[j].x; v[4 * j + 1] = pf[j].y; v[4 * j + 2] = pf[j].z; v[4 * j + 3] = pf[j].w; }
             low_layers<true>(v, t1, t2, t3);
