@@ -191,10 +191,14 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
     const u32 rows = (u32)((n_nodes + stride - 1) / stride);
     const size_t last_node = n_nodes - 1;
     u32 cur[16], nxt[16];
+    // word `node` of column k = scalar base (kernel argument) + ONE 32-bit byte offset shared by all columns: global_load with
+    // an SGPR base and a VGPR offset, instead of a 64-bit address pair per column in VGPRs (columns are at most 4 GiB: the
+    // host takes this kernel for log_size <= 30 only)
+    auto word = [&](int k, u32 byte_off) -> u32 { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)cols.p[k] + byte_off); };
     {
-        const size_t nc = min(node0, last_node);
+        const u32 oc = (u32)min(node0, last_node) * 4u;
 #pragma unroll
-        for (int k = 0; k < 16; k++) cur[k] = cols.p[k][nc];
+        for (int k = 0; k < 16; k++) cur[k] = word(k, oc);
     }
     for (u32 j = 0; j < rows; j++) {
         const size_t node = node0 + (size_t)j * stride;
@@ -205,9 +209,9 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
         for (int b = 0; b < NBLK; b++) {
             // fetch the next 64-byte block (next block of this node, or block 0 of the lane's next node) while this one is compressed
             const int bn = (b + 1) % NBLK;
-            const size_t src = (b + 1 < NBLK) ? nc : nn;
+            const u32 src = (u32)((b + 1 < NBLK) ? nc : nn) * 4u;
 #pragma unroll
-            for (int k = 0; k < 16; k++) nxt[k] = cols.p[16 * bn + k][src];
+            for (int k = 0; k < 16; k++) nxt[k] = word(16 * bn + k, src);
             b2s_compress(h, cur, 64u * (b + 1), b == NBLK - 1);
 #pragma unroll
             for (int k = 0; k < 16; k++) cur[k] = nxt[k];
@@ -227,12 +231,14 @@ __global__ void __launch_bounds__(256) k_merkle_leaf4(const u32 *__restrict__ c0
     const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 rows = (u32)((n_nodes + stride - 1) / stride);
     const size_t last_node = n_nodes - 1;
-    size_t nc = min(node0, last_node);
-    u32 a = c0[nc], b = c1[nc], c = c2[nc], d = c3[nc];
+    auto word = [&](const u32 *col, u32 byte_off) -> u32 { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)col + byte_off); };
+    const u32 o0 = (u32)min(node0, last_node) * 4u;       // scalar base + one 32-bit offset (log_size <= 30: host)
+    u32 a = word(c0, o0), b = word(c1, o0), c = word(c2, o0), d = word(c3, o0);
     for (u32 j = 0; j < rows; j++) {
         const size_t node = node0 + (size_t)j * stride;
         const size_t nn = min(node + stride, last_node);
-        const u32 na = c0[nn], nb = c1[nn], ncc = c2[nn], nd = c3[nn];      // next node's words in flight during the compression
+        const u32 on = (u32)nn * 4u;
+        const u32 na = word(c0, on), nb = word(c1, on), ncc = word(c2, on), nd = word(c3, on);      // next node's words in flight during the compression
         u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
         const u32 m[16] = {a, b, c, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         b2s_compress(h, m, 16u, true);
@@ -526,7 +532,7 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
     static const unsigned cap_mult = getenv("TSTWO_MERKLE_CAP") ? (unsigned)atoi(getenv("TSTWO_MERKLE_CAP")) : 32u;
     const unsigned cap = (unsigned)c.n_cus * cap_mult;     // workgroups per CU before lanes grid-stride over more nodes
     if (blocks > cap) blocks = cap;
-    if (!prev && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !getenv("TSTWO_MERKLE_GENERIC")) {
+    if (!prev && log_size <= 30 && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !getenv("TSTWO_MERKLE_GENERIC")) {
         HashColPtrs hp;
         for (size_t k = 0; k < n_cols; k++) hp.p[k] = cols[k];
         switch (n_cols / 16) {
@@ -538,7 +544,7 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
     }
-    if (!prev && n_cols == 4 && !getenv("TSTWO_MERKLE_GENERIC")) {
+    if (!prev && log_size <= 30 && n_cols == 4 && !getenv("TSTWO_MERKLE_GENERIC")) {
         hipLaunchKernelGGL(k_merkle_leaf4, dim3(blocks), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)out, n_nodes);
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
