@@ -211,8 +211,17 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
             const int bn = (b + 1) % NBLK;
             const u32 src = (u32)((b + 1 < NBLK) ? nc : nn) * 4u;
 #pragma unroll
+#ifdef TSTWO_EXP_LEAF_NOLOAD      // experiment: the kernel's ALU side alone (WRONG results)
+            for (int k = 0; k < 16; k++) nxt[k] = cur[(k + 1) & 15] + src;
+#else
             for (int k = 0; k < 16; k++) nxt[k] = word(16 * bn + k, src);
+#endif
+#ifdef TSTWO_EXP_LEAF_NOHASH      // experiment: the kernel's memory side alone (WRONG results)
+#pragma unroll
+            for (int k = 0; k < 16; k++) h[k & 7] ^= cur[k];
+#else
             b2s_compress(h, cur, 64u * (b + 1), b == NBLK - 1);
+#endif
 #pragma unroll
             for (int k = 0; k < 16; k++) cur[k] = nxt[k];
         }
@@ -275,6 +284,56 @@ __global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ 
         }
         c[0] = cn[0]; c[1] = cn[1]; c[2] = cn[2]; c[3] = cn[3];
     }
+}
+
+// (3) LEVELS column-free layers in one launch, no exchange at all: a lane owns 2^LEVELS consecutive nodes of layer
+// `log_child` — a whole subtree — and produces the 2^(LEVELS-1), ..., 1 nodes above them in post-order (left, right, parent),
+// so that a parent's message is the two digests still in registers.  Every lane is busy at every level (a layer-per-launch
+// chain halves the grid each time and ends in launches that are all latency), intermediate layers are written once and
+// never read back, and two or three launches disappear.  All levels are written to their places in the layers buffer
+// (MerkleProver keeps all layers, vcs/prover.ts:24-29; layer k at byte offset 32*(2^k - 1)).
+struct Digest { u32 w[8]; };
+__device__ __forceinline__ Digest hash_pair(const Digest &l, const Digest &r) {
+    Digest d = {{IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7}};
+    const u32 m[16] = {l.w[0], l.w[1], l.w[2], l.w[3], l.w[4], l.w[5], l.w[6], l.w[7], r.w[0], r.w[1], r.w[2], r.w[3], r.w[4], r.w[5], r.w[6], r.w[7]};
+    b2s_compress(d.w, m, 64u, true);
+    return d;
+}
+__device__ __forceinline__ Digest load_digest(const uint4 *p) {
+    const uint4 a = p[0], b = p[1];
+    return {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void store_digest(uint4 *p, const Digest &d) {
+    p[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+    p[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+}
+// node `idx` of layer `log_child - LVL` (LVL levels above the children) of the lane's subtree; children read from HBM at LVL == 1.
+// The two sub-subtrees are a rolled loop (one copy of each level's compression in the code: fully inlined, the 7 or 15
+// compressions of a kernel took the compiler tens of minutes).
+template <int LVL>
+__device__ __forceinline__ Digest subtree_node(uint4 *__restrict__ layers, u32 log_child, size_t idx) {
+    Digest l, r;
+    if constexpr (LVL == 1) {
+        const uint4 *c = layers + 2 * ((((size_t)1 << log_child) - 1) + 2 * idx);
+        l = load_digest(c);
+        r = load_digest(c + 2);
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            const Digest d = subtree_node<LVL - 1>(layers, log_child, 2 * idx + s);
+            if (s == 0) l = d;
+            else r = d;
+        }
+    }
+    const Digest d = hash_pair(l, r);
+    store_digest(layers + 2 * ((((size_t)1 << (log_child - LVL)) - 1) + idx), d);
+    return d;
+}
+template <int LEVELS>
+__global__ void __launch_bounds__(256) k_merkle_subtree(uint4 *__restrict__ layers, u32 log_child) {
+    const size_t top = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         // node index in layer log_child - LEVELS
+    if (top >= ((size_t)1 << (log_child - LEVELS))) return;
+    (void)subtree_node<LEVELS>(layers, log_child, top);
 }
 
 // Several column-free levels per launch: a workgroup of WG lanes owns 2*WG consecutive nodes of layer `log_child`
@@ -801,6 +860,7 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
     // layers below 2^up_log nodes are latency-bound: fused multi-level launches (k_merkle_upq) instead of one per level
     static const int up_log = getenv("TSTWO_MERKLE_UP_LOG") ? atoi(getenv("TSTWO_MERKLE_UP_LOG"))
                               : (getenv("TSTWO_MERKLE_UP_ONELANE") ? 15 : 16);
+    static const int sub_levels = [] { const char *e = getenv("TSTWO_MERKLE_SUBTREE"); int v = e ? atoi(e) : 2; return v > 4 ? 4 : v; }();   // measured: 2 (0.308 ms) < off (0.313) < 3 (0.326) < 4 (0.332) for 32 x 2^22
     const u32 **lc = n_cols ? new const u32 *[n_cols] : nullptr;
     const uint8_t *prev = nullptr;
     int rc = TSTWO_OK;
@@ -824,6 +884,30 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
             prev = layers + 32 * (((size_t)1 << stop) - 1);
             lg = stop - 1;
             continue;
+        }
+        if (k == 0 && prev != nullptr && sub_levels >= 2) {
+            // a run of column-free layers at or above 2^up_log nodes: in-lane subtrees, up to sub_levels layers per launch
+            int run = 1;
+            while (run < sub_levels && lg - run >= up_log && lg - run >= 0) {
+                bool has = false;
+                for (size_t i = 0; i < n_cols; i++) has = has || log_sizes[i] == (u32)(lg - run);
+                if (has) break;
+                run++;
+            }
+            if (run >= 2) {
+                const size_t tops = (size_t)1 << (lg - run + 1);
+                const unsigned blocks = ceil_div(tops, 256);
+                Context &c = ctx();
+                switch (run) {
+                    case 2: hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(blocks), dim3(256), 0, c.stream, (uint4 *)layers, (u32)lg + 1); break;
+                    case 3: hipLaunchKernelGGL(k_merkle_subtree<3>, dim3(blocks), dim3(256), 0, c.stream, (uint4 *)layers, (u32)lg + 1); break;
+                    default: hipLaunchKernelGGL(k_merkle_subtree<4>, dim3(blocks), dim3(256), 0, c.stream, (uint4 *)layers, (u32)lg + 1); break;
+                }
+                if (hipGetLastError() != hipSuccess) rc = set_error(TSTWO_ERR_HIP, "merkle: subtree kernel launch failed");
+                lg -= run;
+                prev = layers + 32 * (((size_t)1 << (lg + 1)) - 1);
+                continue;
+            }
         }
         rc = commit_layer((u32)lg, prev, lc, k, dst);
         prev = dst;
