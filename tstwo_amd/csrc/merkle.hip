@@ -225,10 +225,18 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
 #pragma unroll
             for (int k = 0; k < 16; k++) cur[k] = nxt[k];
         }
+#ifdef TSTWO_EXP_LEAF_COALESCED_STORE      // experiment: upper bound of coalesced digest stores (WRONG layout)
+        if (node < n_nodes) {
+            const size_t wb = 2 * (node - (threadIdx.x & 63));
+            out[wb + (threadIdx.x & 63)] = make_uint4(h[0], h[1], h[2], h[3]);
+            out[wb + 64 + (threadIdx.x & 63)] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+#else
         if (node < n_nodes) {
             out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
             out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
         }
+#endif
     }
 }
 
