@@ -119,6 +119,22 @@ __device__ __forceinline__ void bf_layer(u32 (&x)[N], u32 (&y)[N], const u32 (&t
     }
 }
 
+// v[i] *= t (t2 = 2t, wave-uniform): the 2^-n scale of the last inverse pass, in the same phases (leaves kPrioHeavy)
+__device__ __forceinline__ void mul8_dbl(u32 (&v)[8], u32 t2) {
+    const u32 P = vgpr_P();
+    u32 s[8], d[8];
+    u64 p[8];
+    phase<kPrioHeavy>(v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = (u64)v[i] * (u64)t2;
+    phase<kPrioLight>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) { s[i] = (u32)(p[i] >> 32) + ((u32)p[i] >> 1); d[i] = s[i] - P; }
+    phase<kPrioHeavy>(d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = min(s[i], d[i]);
+}
+
 // Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits vmcnt(0), which would
 // serialise the in-flight prefetch loads / tile stores behind every stage (guide §5 "Pipelining across
 // barriers"); global memory is never shared between lanes inside these kernels, so LDS ordering suffices.

@@ -165,6 +165,17 @@ __device__ __forceinline__ void low_layers(u32 (&v)[16], const u32 (&t1)[4], con
 __device__ __forceinline__ uint4 scale4(uint4 x, u32 s) {
     return make_uint4(m31_mul(x.x, s), m31_mul(x.y, s), m31_mul(x.z, s), m31_mul(x.w, s));
 }
+// all 16 words of a lane times `s` (the 2^-n of the last inverse pass), in priority phases; returns at kPrioLight
+__device__ __forceinline__ void scale16(uint4 (&x)[4], u32 s) {
+    const u32 s2 = s + s;
+    u32 a[8] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w};
+    u32 b[8] = {x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+    mul8_dbl(a, s2);
+    mul8_dbl(b, s2);
+    phase<kPrioLight>(a, b);
+    x[0] = make_uint4(a[0], a[1], a[2], a[3]); x[1] = make_uint4(a[4], a[5], a[6], a[7]);
+    x[2] = make_uint4(b[0], b[1], b[2], b[3]); x[3] = make_uint4(b[4], b[5], b[6], b[7]);
+}
 
 // optional second pointer table of a kernel (a read-only source); an empty struct when the kernel works in place
 struct NoSrc {};
@@ -216,7 +227,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
         const u32 *__restrict__ d = src_of(col0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            pf[j] = gload4(d + (INV ? 16 * t + 4 * j : 4 * t + j * QT));
+            pf[j] = INV ? gload4(d, 16 * t + 4 * j) : gload4(d + 4 * t + j * QT);
         uint4 q1 = gload4(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)) + 4 * t);
         uint2 q2 = gload2(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)) + 2 * t);
         u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << (LOGT - 4)) + t)];
@@ -249,7 +260,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             }
             lds_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; j++) pf[j] = gload4(next + 4 * t + j * QT);
+            for (int j = 0; j < 4; j++) pf[j] = gload4(next + 4 * t + j * QT);   // (pointer form: the base + 32-bit offset form costs this kernel registers it does not have: +17 us)
             lds_stage<GM, 8, LOGT, THREADS, false>(lds, twl);              // layers LOGT-3..8
             lds_barrier();
             lds_stage<4, 4, LOGT, THREADS, false>(lds, twl);               // layers 7..4
@@ -286,7 +297,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
             lds_wave_fence();    // the next stage reads the blocks this wave has just written
 #pragma unroll
-            for (int j = 0; j < 4; j++) pf[j] = gload4(next + 16 * t + 4 * j);
+            for (int j = 0; j < 4; j++) pf[j] = gload4(next, 16 * t + 4 * j);
             lds_stage<4, 4, LOGT, THREADS, true>(lds, twl);
             lds_barrier();
             lds_stage<GM, 8, LOGT, THREADS, true>(lds, twl);
@@ -299,11 +310,9 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             }
             lds_barrier();       // last LDS access of this column (see the forward branch)
             top_layers<true, true>(x, ta, tb0, tb1);
+            if (scale) scale16(x, scale);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (scale) x[j] = scale4(x[j], scale);
-                gstore4(data + 4 * t + j * QT, x[j]);
-            }
+            for (int j = 0; j < 4; j++) gstore4(data, 4 * t + j * QT, x[j]);
         }
     }
     }   // runs of one tile
@@ -381,6 +390,8 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
     };
 
     if constexpr (!INV || R == 0) {
+        // (column accesses in pointer form here: with the base + 32-bit-offset form of the inverse branch this kernel is 4 us
+        // faster and the bottom pass that follows it 17 us slower — same bottom-pass code, measured twice on one box)
         // forward (and the LDS-free case): four quarter-tile vectors per lane
         uint4 pf[4];
         // loads of the lane's four quarter-tile vectors (j = 2 * top bit + second bit); with EXT the vectors that differ
@@ -472,7 +483,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(d + goff(e_final(tt, g, m)));
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(d, goff(e_final(tt, g, m)));
         }
         stage_twiddles();
         lds_barrier();       // the inverse reads the heap in its first stage, before any other barrier
@@ -500,7 +511,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
 #pragma unroll
             for (int g = 0; g < (16 >> G2); g++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(next + goff(e_final(tt, g, m)));
+                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(next, goff(e_final(tt, g, m)));
             if constexpr (G1 > 0) {
                 lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl);
                 lds_barrier();
@@ -513,11 +524,9 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
             }
             lds_barrier();       // last LDS access of this column
             top_layers<true, F == 2>(x, ta, tb0, tb1);
+            if (scale) scale16(x, scale);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (scale) x[j] = scale4(x[j], scale);
-                gstore4(data + goff(4 * t + j * QT), x[j]);
-            }
+            for (int j = 0; j < 4; j++) gstore4(data, goff(4 * t + j * QT), x[j]);
         }
     }
     }   // runs of one tile

@@ -134,6 +134,20 @@ __device__ __forceinline__ void gstore4(u32 *p, uint4 x) {
     *(TSTWO_GLOBAL u32x4_t *)p = v;
 }
 __device__ __forceinline__ void gstore1(u32 *p, u32 x) { *(TSTWO_GLOBAL u32 *)p = x; }
+// The same with the address split into a (wave-uniform) base and a 32-bit WORD offset below 2^30: the byte offset is formed in
+// 32 bits, so the access is `global_load/store v, v_off, s[base]` — no 64-bit address pair per access in VGPRs and no
+// v_lshl_add_u64 / v_add_co + v_addc (heavy VALU) to build one.
+__device__ __forceinline__ uint4 gload4(const u32 *base, u32 word_off) {
+    const u32x4_t v = *(const TSTWO_GLOBAL u32x4_t *)((const TSTWO_GLOBAL char *)base + (word_off << 2));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ u32 gload1(const u32 *base, u32 word_off) { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)base + (word_off << 2)); }
+__device__ __forceinline__ void gstore4(u32 *base, u32 word_off, uint4 x) {
+    u32x4_t v;
+    v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+    *(TSTWO_GLOBAL u32x4_t *)((TSTWO_GLOBAL char *)base + (word_off << 2)) = v;
+}
+__device__ __forceinline__ void gstore1(u32 *base, u32 word_off, u32 x) { *(TSTWO_GLOBAL u32 *)((TSTWO_GLOBAL char *)base + (word_off << 2)) = x; }
 // Column pointer i.  Written as a branch, not as `c.ext ? c.ext[i] : c.p[i]`: the compiler merged that into ONE load through a
 // selected generic address — a flat_load for the pointer and flat_loads for every column access derived from it.
 __device__ __forceinline__ u32 *colp(const ColPtrs &c, u32 i) {
