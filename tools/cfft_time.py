@@ -17,6 +17,7 @@ ap.add_argument("--cols", type=int, default=32)
 ap.add_argument("--log", type=int, default=22)
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--inv", action="store_true")
+ap.add_argument("--split", type=int, default=1, help="transform the columns in SPLIT groups, one call per group (Infinity Cache reuse between the passes)")
 ap.add_argument("--series", type=int, default=0, help="also print the mean of every SERIES consecutive repetitions (clock behaviour over time)")
 a = ap.parse_args()
 L.init(0)
@@ -31,6 +32,8 @@ for _ in range(a.cols):
 tw, itw = L.DeviceBuffer(4 * (N // 2)), L.DeviceBuffer(4 * (N // 2))
 L.call("tstwo_twiddles_build", half, n - 1, C.c_void_p(tw.ptr), C.c_void_p(itw.ptr))
 ptrs = L.ptr_array([b.ptr for b in bufs])
+gsz = a.cols // a.split
+groups = [L.ptr_array([b.ptr for b in bufs[g * gsz:(g + 1) * gsz]]) for g in range(a.split)]
 name = "tstwo_cfft_interpolate" if a.inv else "tstwo_cfft_evaluate"
 t = itw if a.inv else tw
 for _ in range(3):
@@ -40,7 +43,11 @@ series = []
 for _ in range(a.reps):
     e0, e1 = L.Event(), L.Event()
     e0.record()
-    L.call(name, ptrs, a.cols, n, half, C.c_void_p(t.ptr), n - 1)
+    if a.split == 1:
+        L.call(name, ptrs, a.cols, n, half, C.c_void_p(t.ptr), n - 1)
+    else:
+        for gp in groups:
+            L.call(name, gp, gsz, n, half, C.c_void_p(t.ptr), n - 1)
     e1.record()
     ms = e0.elapsed_ms(e1)
     best, tot = min(best, ms), tot + ms

@@ -73,12 +73,6 @@ __device__ __forceinline__ void ibf_dbl(u32 &v0, u32 &v1, u32 t2) {
 }
 
 // ---- butterflies in priority phases (the issue model and TSTWO_PHASE: common.h)
-// The modulus sits in a VGPR: a literal operand makes v_add / v_sub heavy.
-__device__ __forceinline__ u32 vgpr_P() {
-    u32 p = M31_P;
-    asm("" : "+v"(p));
-    return p;
-}
 // N independent butterflies (x[i], y[i]) with doubled twiddles t2[i]; leaves the wave at kPrioHeavy (the next layer starts
 // heavy as well) — the caller drops to kPrioLight after its last layer.
 template <bool INV, int N>

@@ -14,6 +14,9 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define M31_P 2147483647u
+#ifdef __HIPCC__
+#include "phase.cuh"
+#endif
 
 __device__ __forceinline__ u32 m31_add(u32 a, u32 b) {
     u32 s = a + b;               // < 2P < 2^32
@@ -90,12 +93,63 @@ __device__ __forceinline__ qm31 qm31_neg(qm31 x) { return {m31_neg(x.a), m31_neg
 __device__ __forceinline__ cm31 cm31_mul_R(cm31 z) {
     return {m31_sub(m31_double(z.a), z.b), m31_add(z.a, m31_double(z.b))};
 }
-// (a0b0 + R a1b1, a0b1 + a1b0), fields/qm31.ts:223-233
-__device__ __forceinline__ qm31 qm31_mul(qm31 x, qm31 y) {
+// (a0b0 + R a1b1, a0b1 + a1b0), fields/qm31.ts:223-233 — the reference's formulation, kept as the readable statement of
+// what qm31_mul below computes (and used by it nowhere)
+__device__ __forceinline__ qm31 qm31_mul_ref(qm31 x, qm31 y) {
     cm31 a0 = q_c0(x), a1 = q_c1(x), b0 = q_c0(y), b1 = q_c1(y);
     cm31 c0 = cm31_add(cm31_mul(a0, b0), cm31_mul_R(cm31_mul(a1, b1)));
     cm31 c1 = cm31_add(cm31_mul(a0, b1), cm31_mul(a1, b0));
     return q_make(c0, c1);
+}
+// The same product written out over the four M31 coordinates, with every minus sign moved into an operand (P - y) and
+// every factor 2 into an operand (2y < 2^32), so that each coordinate is a sum of products accumulated in 64 bits by
+// v_mad_u64_u32 chains — at most 4 "units" of (P-1)P < 2^62 per accumulator, 4 (2^62 - 3 2^31 + 2) < 2^64:
+//   r0 = [x0 y0 + x1 (P-y1) + x2 (2 y2)] + [x3 (2(P-y3)) + x2 (P-y3) + x3 (P-y2)]      (re of a0 b0 + (2+i) a1 b1)
+//   r1 = [x0 y1 + x1 y0 + x2 y2 + x3 (P-y3)] + [x2 (2 y3) + x3 (2 y2)]                 (im of the same)
+//   r2 =  x0 y2 + x1 (P-y3) + x2 y0 + x3 (P-y1)                                         (re of a0 b1 + a1 b0)
+//   r3 =  x0 y3 + x1 y2 + x2 y1 + x3 y0                                                 (im)
+// 20 multiply-adds and 6 reductions instead of 16 multiplies, 16 reductions and 14 modular additions (~132 -> ~105
+// instructions), and the six accumulators are independent, so the whole product is issued in priority phases (phase.cuh):
+// 20 x v_mad_u64_u32 | 12 light | 6 x v_alignbit | 30 light | 6 x v_min | 18 light | 6 x v_min.
+// Reduction of a 64-bit x = t1 + 2^31 t2 + 2^63 t3 (t1 31 bits, t2 32 bits, t3 one bit): 2^31 = 1, 2^63 = 2 (mod P), and
+// t2 = u + 2^31 w, so x = t1 + u + w + 2 t3: s = t1 + u <= 2P -> one conditional subtract (<= P), + w + 2 t3 <= P + 3 ->
+// one more: canonical.  Canonical in, canonical out; bit-identical to qm31_mul_ref (tests: the reference's qm31 vectors
+// through tstwo_qm31_mul, the fuzz suite).
+__device__ __forceinline__ qm31 qm31_mul(qm31 x, qm31 y) {
+    const u32 P = vgpr_P();
+    u32 pre[6] = {P - y.b, P - y.c, P - y.d, y.c + y.c, y.d + y.d, 0u};     // ny1, ny2, ny3, dy2, dy3, dny3
+    pre[5] = pre[2] + pre[2];
+    phase<kPrioHeavy>(pre);
+    const u32 ny1 = pre[0], ny2 = pre[1], ny3 = pre[2], dy2 = pre[3], dy3 = pre[4], dny3 = pre[5];
+    u64 acc[6];
+    acc[0] = (u64)x.a * y.a;  acc[1] = (u64)x.d * dny3; acc[2] = (u64)x.a * y.b; acc[3] = (u64)x.c * dy3;
+    acc[4] = (u64)x.a * y.c;  acc[5] = (u64)x.a * y.d;
+    acc[0] += (u64)x.b * ny1; acc[1] += (u64)x.c * ny3; acc[2] += (u64)x.b * y.a; acc[3] += (u64)x.d * dy2;
+    acc[4] += (u64)x.b * ny3; acc[5] += (u64)x.b * y.c;
+    acc[0] += (u64)x.c * dy2; acc[1] += (u64)x.d * ny2; acc[2] += (u64)x.c * y.c;
+    acc[4] += (u64)x.c * y.a; acc[5] += (u64)x.c * y.b;
+    acc[2] += (u64)x.d * ny3; acc[4] += (u64)x.d * ny1; acc[5] += (u64)x.d * y.a;
+    phase<kPrioLight>(acc);
+    u32 t1[6], t3[6], t2[6], s[6], d[6], w[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { t1[i] = (u32)acc[i] & P; t3[i] = (u32)(acc[i] >> 32) >> 31; }
+    phase<kPrioHeavy>(t1, t3);
+#pragma unroll
+    for (int i = 0; i < 6; i++) t2[i] = __builtin_amdgcn_alignbit((u32)(acc[i] >> 32), (u32)acc[i], 31);
+    phase<kPrioLight>(t2);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { s[i] = t1[i] + (t2[i] & P); w[i] = (t2[i] >> 31) + t3[i]; d[i] = s[i] - P; }
+    phase<kPrioHeavy>(d, w);
+#pragma unroll
+    for (int i = 0; i < 6; i++) s[i] = min(s[i], d[i]);
+    phase<kPrioLight>(s);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { s[i] = s[i] + w[i] + t3[i]; d[i] = s[i] - P; }
+    phase<kPrioHeavy>(d);
+#pragma unroll
+    for (int i = 0; i < 6; i++) s[i] = min(s[i], d[i]);
+    phase<kPrioLight>(s);
+    return {m31_add(s[0], s[1]), m31_add(s[2], s[3]), s[4], s[5]};
 }
 __device__ __forceinline__ qm31 qm31_mul_m31(qm31 x, u32 m) {
     return {m31_mul(x.a, m), m31_mul(x.b, m), m31_mul(x.c, m), m31_mul(x.d, m)};
