@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
         for (int s = 7; s >= 0; s--) {
             cm31 dinv = s == 0 ? cur : cm31_mul(pre[s - 1], cur);
             cur = cm31_mul(cur, den[s]);
-            acc[s] = qm31_add(qm31_mul(acc[s], bc.coeff), qm31_mul_cm31(num[s], dinv));
+            const qm31 term = qm31_mul_cm31(num[s], dinv);
+            acc[s] = b == 0 ? term : qm31_add(qm31_mul(acc[s], bc.coeff), term);     // the accumulator is zero before the first batch
         }
     }
     if (zero) atomicOr(flag, 1u);
