@@ -21,11 +21,11 @@ cd $R
 python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/cfft_pmc.json
 python3 tools/sq_summary.py $O/pmc_sq1 $O/pmc_sq2 > $O/sq_counters.json
 # 2. the bench line (configs 1-4 inside), with the traffic of THIS build
-$T 500 python3 bench.py --steps 20 --warmup 3 --pmc-json $O/cfft_pmc.json > $O/bench.json 2> $O/bench.err
+$T 500 python3 bench.py --steps 20 --warmup 5 --pmc-json $O/cfft_pmc.json > $O/bench.json 2> $O/bench.err
 echo "bench done"; tail -c 300 $O/bench.json
 # 3. kernel trace + stats of the same command (without the CPU leg and the config sweep) and of the config sweep
 cd /tmp
-$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-configs > $O/stats.log 2>&1
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-configs > $O/stats.log 2>&1
 echo "stats done"
 $T 300 rocprofv3 --kernel-trace --output-format csv -d $O/stats_configs -o configs -- python3 $R/tools/bench_configs.py --no-cpu > $O/stats_configs.log 2>&1
 echo "stats configs done"
