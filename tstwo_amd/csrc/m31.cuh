@@ -35,6 +35,17 @@ __device__ __forceinline__ u32 m31_reduce64(u64 p) {  // p < 2^62: fields/m31.ts
     return min(s, s - M31_P);
 }
 __device__ __forceinline__ u32 m31_mul(u32 a, u32 b) { return m31_reduce64((u64)a * (u64)b); }
+// any x < 2^64 -> canonical: x = t1 + 2^31 t2 + 2^63 t3 (31 + 32 + 1 bits) = t1 + (t2 & P) + (t2 >> 31) + 2 t3 (mod P); the form
+// qm31_mul uses (3 heavy + 10 light instructions; no 64-bit adds)
+__device__ __forceinline__ u32 m31_reduce_u64(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    const u32 t2 = __builtin_amdgcn_alignbit(hi, lo, 31), t3 = hi >> 31;
+    u32 s = (lo & M31_P) + (t2 & M31_P);      // <= 2P
+    s = min(s, s - M31_P);                    // <= P
+    s = s + (t2 >> 31) + t3 + t3;             // <= P + 3
+    return min(s, s - M31_P);
+}
+
 __device__ __forceinline__ u32 m31_sqr(u32 a) { return m31_mul(a, a); }
 // a*b + c*d with one reduction (products < 2^62 each, sum < 2^63)
 __device__ __forceinline__ u32 m31_mul_add_mul(u32 a, u32 b, u32 c, u32 d) {

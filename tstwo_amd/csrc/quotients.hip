@@ -65,24 +65,48 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
 
     for (u32 b = 0; b < n_batches; b++) {
         const BatchConst bc = batches[b];
-        qm31 num[8];
+        // numerator: sum_j c_j * f_j(row) accumulated lazily — up to 4 products of < 2^62 (plus the 31-bit running value) fit
+        // 64 bits, so a group of 4 column entries costs 4 v_mad_u64_u32 and ONE reduction per coordinate and row instead of
+        // 4 multiplications with a reduction each and 4 modular additions
+        u32 num[4][8];
 #pragma unroll
-        for (int s = 0; s < 8; s++) num[s] = {0u, 0u, 0u, 0u};
-        for (u32 j = bc.begin; j < bc.end; j++) {
-            const Entry en = entries[j];
-            const u32 *col = cols[en.col];
-            uint4 f0 = gload4(col + row0);
-            uint4 f1 = gload4(col + row0 + 4);
-            u32 f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int s = 0; s < 8; s++) num[s] = qm31_add(num[s], qm31_mul_m31(en.c, f[s]));
+            for (int s = 0; s < 8; s++) num[k][s] = 0u;
+        for (u32 j = bc.begin; j < bc.end; j += 4) {
+            const u32 cnt = min(4u, bc.end - j);                    // wave-uniform
+            u32 cw[4][4], f[4][8];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const Entry en = entries[j + (e < (int)cnt ? e : 0)];          // loads are never branched around; unused products get c = 0
+                const u32 *col = cols[en.col];
+                const uint4 f0 = gload4(col + row0), f1 = gload4(col + row0 + 4);
+                f[e][0] = f0.x; f[e][1] = f0.y; f[e][2] = f0.z; f[e][3] = f0.w; f[e][4] = f1.x; f[e][5] = f1.y; f[e][6] = f1.z; f[e][7] = f1.w;
+                const bool on = e < (int)cnt;
+                cw[e][0] = on ? en.c.a : 0u; cw[e][1] = on ? en.c.b : 0u; cw[e][2] = on ? en.c.c : 0u; cw[e][3] = on ? en.c.d : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    u64 a = (u64)num[k][s];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) a += (u64)cw[e][k] * (u64)f[e][s];
+                    num[k][s] = m31_reduce_u64(a);
+                }
         }
+        // denominator, linear in the point: (Pr.x - x) Pi.y - (Pr.y - y) Pi.x = (Pr.x Pi.y - Pr.y Pi.x) - x Pi.y + y Pi.x, i.e. per
+        // coordinate C0 + x (P - Pi.y) + y Pi.x: two multiply-adds on top of a per-batch constant and one reduction
+        const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));
+        const u32 npya = M31_P - bc.piy.a, npyb = M31_P - bc.piy.b;
         cm31 den[8], pre[8];
+        qm31 numq[8];
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            num[s] = qm31_sub(num[s], qm31_add(qm31_mul_m31(bc.A, pt[s].y), bc.B));
-            cm31 dx = cm31_sub(bc.prx, cm31{pt[s].x, 0u}), dy = cm31_sub(bc.pry, cm31{pt[s].y, 0u});
-            cm31 d = cm31_sub(cm31_mul(dx, bc.piy), cm31_mul(dy, bc.pix));
+            numq[s] = qm31_sub({num[0][s], num[1][s], num[2][s], num[3][s]}, qm31_add(qm31_mul_m31(bc.A, pt[s].y), bc.B));
+            cm31 d;
+            d.a = m31_reduce_u64((u64)c0.a + (u64)pt[s].x * npya + (u64)pt[s].y * bc.pix.a);
+            d.b = m31_reduce_u64((u64)c0.b + (u64)pt[s].x * npyb + (u64)pt[s].y * bc.pix.b);
             if (cm31_is_zero(d)) { zero = true; d = {1u, 0u}; }
             den[s] = d;
             pre[s] = s == 0 ? d : cm31_mul(pre[s - 1], d);
@@ -92,7 +116,7 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
         for (int s = 7; s >= 0; s--) {
             cm31 dinv = s == 0 ? cur : cm31_mul(pre[s - 1], cur);
             cur = cm31_mul(cur, den[s]);
-            const qm31 term = qm31_mul_cm31(num[s], dinv);
+            const qm31 term = qm31_mul_cm31(numq[s], dinv);
             acc[s] = b == 0 ? term : qm31_add(qm31_mul(acc[s], bc.coeff), term);     // the accumulator is zero before the first batch
         }
     }
