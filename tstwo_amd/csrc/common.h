@@ -17,6 +17,7 @@ struct Context {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;     // stream every launch goes to (own_stream or a borrowed one)
     cpoint *gen_pow2 = nullptr;       // device: GEN * 2^k, k = 0..30 (circle.ts:137)
+    cpoint *gen_win = nullptr;        // device: 4 windows x 256 entries, [w][k] = (k * 2^(8w)) * GEN: idx * GEN in 3 point additions
     u32 *flag = nullptr;              // device: error flag word (zero-inverse detection)
     u32 *scratch = nullptr;           // device scratch for reductions (decompose / eval_at_point)
     size_t scratch_bytes = 0;

@@ -240,6 +240,20 @@ int tstwo_init(int device) {
     }
     TSTWO_HIP(hipMalloc((void **)&c.gen_pow2, sizeof(tab)));
     TSTWO_HIP(hipMemcpy(c.gen_pow2, tab, sizeof(tab), hipMemcpyHostToDevice));
+    {   // windowed multiples: win[w][k] = k * (2^(8w) GEN), k < 256 (the identity at k = 0)
+        static cpoint win[4 * 256];
+        for (int w = 0; w < 4; w++) {
+            const cpoint base = tab[8 * w];
+            cpoint acc = {1u, 0u};
+            for (int k = 0; k < 256; k++) {
+                win[256 * w + k] = acc;
+                const cpoint nx = {h_sub(h_mul(acc.x, base.x), h_mul(acc.y, base.y)), h_add(h_mul(acc.x, base.y), h_mul(acc.y, base.x))};
+                acc = nx;
+            }
+        }
+        TSTWO_HIP(hipMalloc((void **)&c.gen_win, sizeof(win)));
+        TSTWO_HIP(hipMemcpy(c.gen_win, win, sizeof(win), hipMemcpyHostToDevice));
+    }
     TSTWO_HIP(hipMalloc((void **)&c.flag, 64));
     TSTWO_HIP(hipMemset(c.flag, 0, 64));
     if (hipHostMalloc(&c.pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; (void)hipGetLastError(); }
@@ -262,6 +276,7 @@ int tstwo_shutdown(void) {
         g_pool.live.clear();
     }
     if (c.gen_pow2) (void)hipFree(c.gen_pow2);
+    if (c.gen_win) (void)hipFree(c.gen_win);
     if (c.flag) (void)hipFree(c.flag);
     if (c.pinned) (void)hipHostFree(c.pinned);
     if (c.up_ring) {

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) k_twiddles(u32 init, u32 m, u32 *__restri
     u32 k = lg > 1 ? (__brev(j) >> (32 - (lg - 1))) : 0u;
     u32 init_l = (init << lvl) & 0x7fffffffu;    // Coset.double(): initial*2, circle.ts:253-256
     u32 idx = (init_l + (k << (31 - lg))) & 0x7fffffffu;
-    tw[e] = cpoint_from_index(idx, gen_pow2).x;
+    tw[e] = cpoint_from_index_win(idx, gen_pow2).x;      // gen_pow2 = Context::gen_win
 }
 
 __global__ void __launch_bounds__(256) k_extend(const u32 *__restrict__ src, size_t n_src, u32 *__restrict__ dst, size_t n_dst) {
@@ -444,7 +444,7 @@ int tstwo_twiddles_build(u32 coset_initial, u32 log_size, u32 *tw, u32 *itw) {
     if (log_size > 30 || !tw) return set_error(TSTWO_ERR_BAD_ARG, "tstwo_twiddles_build: bad log_size or null buffer");
     size_t n = (size_t)1 << log_size;
     hipLaunchKernelGGL(k_twiddles, dim3(ceil_div(n, 256)), dim3(256), 0, ctx().stream, coset_initial & 0x7fffffffu,
-                       log_size, tw, ctx().gen_pow2);
+                       log_size, tw, ctx().gen_win);
     TSTWO_LAUNCH_CHECK();
     if (itw) return tstwo_m31_batch_inverse(tw, itw, n);   // backend/cpu/circle.ts:223-239 ("0 has no inverse" for cosets through x = 0)
     return TSTWO_OK;

@@ -192,6 +192,16 @@ __device__ __forceinline__ cpoint cpoint_from_index(u32 idx, const cpoint *__res
     return r;
 }
 
+// the same from the windowed table (Context::gen_win: [w][k] = (k 2^(8w)) GEN): 4 lookups and 3 additions instead of one addition
+// per set bit of idx
+__device__ __forceinline__ cpoint cpoint_from_index_win(u32 idx, const cpoint *__restrict__ gen_win) {
+    idx &= 0x7fffffffu;
+    cpoint r = gen_win[idx & 255u];
+    r = cpoint_add(r, gen_win[256u + ((idx >> 8) & 255u)]);
+    r = cpoint_add(r, gen_win[512u + ((idx >> 16) & 255u)]);
+    return cpoint_add(r, gen_win[768u + (idx >> 24)]);
+}
+
 // fft.ts:12-17 / :25-30
 __device__ __forceinline__ void m31_butterfly(u32 &v0, u32 &v1, u32 t) {
     u32 tmp = m31_mul(v1, t);

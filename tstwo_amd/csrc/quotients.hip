@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
     // natural index of row 8t: bitrev(t, log_size-3) inside the half coset (log_size-1), step 2^(31-(log_size-1))
     u32 bt = log_size > 3 ? (__brev((u32)t) >> (32 - (log_size - 3))) : 0u;
     u32 idx0 = (half_initial + (bt << (32 - log_size))) & 0x7fffffffu;
-    cpoint p0 = cpoint_from_index(idx0, gen_pow2);
+    cpoint p0 = cpoint_from_index_win(idx0, gen_pow2);      // gen_pow2 = Context::gen_win for this kernel
     cpoint pt[8];
 #pragma unroll
     for (int s = 0; s < 8; s++) pt[s] = domain_point8(p0, q4, s);
@@ -233,7 +233,7 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         cpoint q4 = {qx, qy};
         size_t n_threads = (size_t)1 << (log_size - 3);
         hipLaunchKernelGGL(k_quotients8, dim3(ceil_div(n_threads, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu,
-                           log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_pow2, q4, c.flag);
+                           log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_win, q4, c.flag);
     } else {
         size_t N = (size_t)1 << log_size;
         hipLaunchKernelGGL(k_quotients_row, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size,
