@@ -49,7 +49,7 @@ __device__ __forceinline__ u32 rotr32(u32 x, int r) { return __builtin_amdgcn_al
     ROUND(STEP, 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13) ROUND(STEP, 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9) \
     ROUND(STEP, 12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11) ROUND(STEP, 13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10) \
     ROUND(STEP, 6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5) ROUND(STEP, 10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
-template <bool PHASED>
+template <bool PHASED, bool STORE = false>
 __global__ void __launch_bounds__(256) k_blake2s(u32 *out, u32 seed, int n_compress) {
     u32 h[8], m[16];
     for (int j = 0; j < 8; j++) h[j] = threadIdx.x * (j + 1) + seed;
@@ -67,6 +67,57 @@ __global__ void __launch_bounds__(256) k_blake2s(u32 *out, u32 seed, int n_compr
         }
         h[0] ^= v0 ^ v8; h[1] ^= v1 ^ v9; h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11; h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
         m[i & 15] ^= h[0];
+    }
+    if (STORE) {      // the leaf kernel's output: a 32-byte digest per lane
+        uint4 *o = reinterpret_cast<uint4 *>(out) + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+        return;
+    }
+    u32 r = 0;
+    for (int j = 0; j < 8; j++) r ^= h[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+// the same with the loop body instantiated twice (two copies of the compression in the code, as in the unrolled NBLK = 2 leaf kernel)
+template <bool PHASED, bool STORE = false>
+__global__ void __launch_bounds__(256) k_blake2s_x2(u32 *out, u32 seed, int n_compress) {
+    u32 h[8], m[16];
+    for (int j = 0; j < 8; j++) h[j] = threadIdx.x * (j + 1) + seed;
+    for (int j = 0; j < 16; j++) m[j] = threadIdx.x + j * seed;
+#pragma unroll 1
+    for (int i0 = 0; i0 < n_compress; i0 += 2) {
+        { const int i = i0;
+        u32 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+        u32 v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au, v12 = 0x510E527Fu ^ (u32)i, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu, v15 = 0x5BE0CD19u;
+        if (PHASED) {
+            phase<kPrioHeavy>(v0, v1, v2, v3);
+            TEN_ROUNDS(STEP_PHASED)
+            phase<kPrioLight>(v4, v5, v6, v7);
+        } else {
+            TEN_ROUNDS(STEP_PLAIN)
+        }
+        h[0] ^= v0 ^ v8; h[1] ^= v1 ^ v9; h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11; h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+        m[i & 15] ^= h[0];
+            }
+        { const int i = i0 + 1;
+        u32 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+        u32 v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au, v12 = 0x510E527Fu ^ (u32)i, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu, v15 = 0x5BE0CD19u;
+        if (PHASED) {
+            phase<kPrioHeavy>(v0, v1, v2, v3);
+            TEN_ROUNDS(STEP_PHASED)
+            phase<kPrioLight>(v4, v5, v6, v7);
+        } else {
+            TEN_ROUNDS(STEP_PLAIN)
+        }
+        h[0] ^= v0 ^ v8; h[1] ^= v1 ^ v9; h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11; h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+        m[i & 15] ^= h[0];
+            }
+    }
+    if (STORE) {      // the leaf kernel's output: a 32-byte digest per lane
+        uint4 *o = reinterpret_cast<uint4 *>(out) + 2 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x);
+        o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        o[1] = make_uint4(h[4], h[5], h[6], h[7]);
+        return;
     }
     u32 r = 0;
     for (int j = 0; j < 8; j++) r ^= h[j];
@@ -90,7 +141,7 @@ int main() {
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 1;
     const int cus = prop.multiProcessorCount;
     u32 *out;
-    if (hipMalloc(&out, (size_t)4 << 22) != hipSuccess) return 1;
+    if (hipMalloc(&out, (size_t)32 << 22) != hipSuccess) return 1;
     for (int i = 0; i < 50; i++) hipLaunchKernelGGL(k_blake2s<false>, dim3(cus * 8), dim3(256), 0, 0, out, 3u, 64);
     (void)hipDeviceSynchronize();
     printf("{\"note\": \"Blake2s compressions/s on register data, G = 1e9\"");
@@ -102,6 +153,10 @@ int main() {
     }
     float p = time_ms([&] { hipLaunchKernelGGL(k_blake2s<false>, dim3((1 << 22) / 256), dim3(256), 0, 0, out, 3u, 2); }, 20);
     float q = time_ms([&] { hipLaunchKernelGGL(k_blake2s<true>, dim3((1 << 22) / 256), dim3(256), 0, 0, out, 3u, 2); }, 20);
+    float qs = time_ms([&] { hipLaunchKernelGGL((k_blake2s<true, true>), dim3((1 << 22) / 256), dim3(256), 0, 0, out, 3u, 2); }, 20);
+    printf(",\n \"leaf-kernel shape with the 32-byte digest stores (134 MB)\": {\"phased_us\": %.1f}", qs * 1e3);
+    float q2 = time_ms([&] { hipLaunchKernelGGL((k_blake2s_x2<true, true>), dim3((1 << 22) / 256), dim3(256), 0, 0, out, 3u, 2); }, 20);
+    printf(",\n \"the same with two copies of the compression in the loop body\": {\"phased_us\": %.1f}", q2 * 1e3);
     printf(",\n \"leaf-kernel shape: 2^22 lanes x 2 compressions\": {\"program_order_G_per_s\": %.1f, \"phased_G_per_s\": %.1f, \"phased_us\": %.1f}\n}\n",
            (double)(1 << 22) * 2 / (p * 1e-3) / 1e9, (double)(1 << 22) * 2 / (q * 1e-3) / 1e9, q * 1e3);
     return 0;
