@@ -379,6 +379,55 @@ def merkle_commit(cols, log_sizes):
     return [flat[(1 << k) - 1:(2 << k) - 1] for k in range(max_log + 1)], bytes(root)
 
 
+def test_qm31_mul_edge_grid():
+    """qm31_mul is six 64-bit multiply-add chains with one reduction each (m31.cuh): every coordinate of both operands runs
+    over the values where a lazy accumulator or the final conditional subtracts could go wrong (0, 1, 2, 2^30, P-2, P-1)."""
+    P = 2**31 - 1
+    edge = np.array([0, 1, 2, 1 << 30, P - 2, P - 1], dtype=np.uint32)
+    g = np.stack(np.meshgrid(edge, edge, edge, edge, indexing="ij"), axis=-1).reshape(-1, 4)      # 1296 QM31 values
+    xi, yi = np.meshgrid(np.arange(len(g)), np.arange(len(g)), indexing="ij")
+    x, y = g[xi.ravel()], g[yi.ravel()]                                                            # 1 679 616 pairs
+    n = len(x)
+    a = [np.ascontiguousarray(x[:, k]) for k in range(4)]
+    b = [np.ascontiguousarray(y[:, k]) for k in range(4)]
+    da, db = [dev(c) for c in a], [dev(c) for c in b]
+    do = [dev_empty(n) for _ in range(4)]
+    L.call("tstwo_qm31_mul", p4(da), p4(db), p4(do), n)
+    exp = orc.qm31_col_mul(a, b)
+    for k in range(4):
+        assert (host(do[k], n) == exp[k]).all()
+
+
+_SUBTREE_SCRIPT = r"""
+import hashlib, sys
+sys.path[:0] = [{root!r}, {tests!r}]
+from test_gpu_capi import rand_column, merkle_commit
+log = 19
+cols = [rand_column(900 + c, 1 << log) for c in range(4)]
+layers, root = merkle_commit(cols, [log] * 4)
+print(bytes(root).hex(), hashlib.blake2s(b"".join(l.tobytes() for l in layers)).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("levels", ["0", "3", "4"])
+def test_merkle_subtree_levels_agree(levels):
+    """TSTWO_MERKLE_SUBTREE is read once per process: every setting (layer per launch, 3 and 4 layers per in-lane subtree;
+    2 is the default the other tests run) must give the oracle's tree."""
+    import os
+    import subprocess
+    import sys
+    log = 19
+    cols = [rand_column(900 + c, 1 << log) for c in range(4)]
+    olayers, oroot = orc.merkle_commit(cols, [log] * 4)
+    want = bytes(oroot).hex() + " " + hashlib.blake2s(b"".join(l.tobytes() for l in olayers)).hexdigest()
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    script = _SUBTREE_SCRIPT.format(root=os.path.dirname(tests_dir), tests=tests_dir)
+    env = dict(os.environ, TSTWO_MERKLE_SUBTREE=levels)
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == want
+
+
 def test_merkle_golden(golden):
     for e in golden["merkle"]:
         cols = [column(e["seed_base"] + i, 1 << lg) for i, lg in enumerate(e["log_sizes"])]
