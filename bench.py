@@ -12,6 +12,9 @@ an all-gather of the ranks' 32-byte Merkle roots (RCCL; N > 1 only).  Inputs are
 (SplitMix64 seeds 100+c) and resident in HBM before the timed region; twiddles are prebuilt.
 The transform is data-oblivious, so each step re-evaluates the previous step's output in place
 (uniform canonical M31 columns again) — no work is skipped or cached.
+Order of a run: one step on the fresh input (its Merkle root is kept and compared with the CPU oracle's -> `root_match`),
+--spinup untimed steps (default 80: the part needs ~50 ms of load before its clocks settle; `spinup_steps` in the line),
+W - 1 more warm-up steps, barrier, K timed steps, barrier.
 
 Rank 0 prints ONE JSON line:  value = (all ranks' columns * 2^22 elements * K) / max-over-ranks time.
 `roofline` prices the dominant kernel (the CFFT pass kernel) against the 8 TB/s HBM roofline with the
