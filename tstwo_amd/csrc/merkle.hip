@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(WG) k_merkle_upq(uint4 *__restrict__ layers, u
 int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
     Context &c = ctx();
     static const bool one_lane = getenv("TSTWO_MERKLE_UP_ONELANE") != nullptr;     // previous scheme, kept for A/B timing
+    static const bool small_wg = getenv("TSTWO_MERKLE_UP_SMALLWG") != nullptr;     // 256-lane workgroups only (A/B timing)
     while (log_child > log_stop) {
         const u32 remaining = log_child - log_stop;
         const u32 parents_log = log_child - 1;
@@ -485,6 +486,9 @@ int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
                 hipLaunchKernelGGL(k_merkle_up<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
                 log_child -= remaining;
             }
+        } else if (parents_log <= 8 && !small_wg) {   // <= 256 parents: ONE workgroup of 256 quads finishes the tree (up to 9 levels)
+            hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1), dim3(1024), 0, c.stream, (uint4 *)layers, log_child, remaining);
+            log_child -= remaining;
         } else if (parents_log >= 6) {            // >= 64 parents: 64 quads per workgroup, 64 -> 1 = up to 7 levels each
             u32 levels = remaining < 7 ? remaining : 7;
             hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1u << (parents_log - 6)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
