@@ -433,17 +433,10 @@ __device__ __forceinline__ void b2s_quad_block64(const u32 (&m)[16], u32 j, u32 
 
 // Levels log_child-1 .. log_child-levels, 4 lanes per node: a workgroup of WG lanes owns WG/4 consecutive parents of the
 // first level and everything above them (WG/4 -> 1 is log2(WG/4)+1 levels).  Children digests live in LDS between levels.
+// the level loop shared by k_merkle_upq and k_merkle_leaf4_upq: `sh` holds the 2*active child digests of this workgroup
 template <int WG>
-__global__ void __launch_bounds__(WG) k_merkle_upq(uint4 *__restrict__ layers, u32 log_child, u32 levels) {
-    constexpr u32 Q = WG / 4;
-    __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];      // 2Q child digests x 8 words
+__device__ __forceinline__ void upq_levels(uint4 *__restrict__ layers, u32 *sh, u32 log_child, u32 levels, u32 active) {
     const u32 t = threadIdx.x, q = t >> 2, j = t & 3;
-    u32 active = min(Q, 1u << (log_child - 1));                   // parents this workgroup produces at the first level
-    {
-        const uint4 *child = layers + 2 * (((size_t)1 << log_child) - 1) + (size_t)blockIdx.x * (4 * active);
-        if (t < 4 * active) reinterpret_cast<uint4 *>(sh)[t] = child[t];      // 2*active digests = 4*active uint4
-    }
-    __syncthreads();
     for (u32 lv = 1; lv <= levels; lv++) {
         const u32 log_out = log_child - lv;
         u32 o_lo = 0, o_hi = 0;
@@ -467,6 +460,43 @@ __global__ void __launch_bounds__(WG) k_merkle_upq(uint4 *__restrict__ layers, u
         __syncthreads();
         active >>= 1;
     }
+}
+template <int WG>
+__global__ void __launch_bounds__(WG) k_merkle_upq(uint4 *__restrict__ layers, u32 log_child, u32 levels) {
+    constexpr u32 Q = WG / 4;
+    __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];      // 2Q child digests x 8 words
+    const u32 t = threadIdx.x;
+    const u32 active = min(Q, 1u << (log_child - 1));             // parents this workgroup produces at the first level
+    {
+        const uint4 *child = layers + 2 * (((size_t)1 << log_child) - 1) + (size_t)blockIdx.x * (4 * active);
+        if (t < 4 * active) reinterpret_cast<uint4 *>(sh)[t] = child[t];      // 2*active digests = 4*active uint4
+    }
+    __syncthreads();
+    upq_levels<WG>(layers, sh, log_child, levels, active);
+}
+// A small 4-column tree (every FRI layer below 2^17 rows) without a launch of its own for the leaves: the first 2*active lanes
+// of the workgroup hash one leaf each (16-byte message, vcs/blake2_merkle.ts:9-24), write it to the leaf layer and to LDS,
+// and the quad levels follow in the same launch.
+template <int WG>
+__global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__ c0, const u32 *__restrict__ c1, const u32 *__restrict__ c2,
+                                                        const u32 *__restrict__ c3, uint4 *__restrict__ layers, u32 log_leaf, u32 levels) {
+    constexpr u32 Q = WG / 4;
+    __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];
+    const u32 t = threadIdx.x;
+    const u32 active = min(Q, 1u << (log_leaf - 1));              // parents of the first level in this workgroup
+    if (t < 2 * active) {
+        const size_t node = (size_t)blockIdx.x * (2 * active) + t;
+        u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+        const u32 m[16] = {c0[node], c1[node], c2[node], c3[node], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        b2s_compress(h, m, 16u, true);
+        uint4 *leaf = layers + 2 * ((((size_t)1 << log_leaf) - 1) + node);
+        const uint4 lo = make_uint4(h[0], h[1], h[2], h[3]), hi = make_uint4(h[4], h[5], h[6], h[7]);
+        leaf[0] = lo; leaf[1] = hi;
+        reinterpret_cast<uint4 *>(sh)[2 * t] = lo;
+        reinterpret_cast<uint4 *>(sh)[2 * t + 1] = hi;
+    }
+    __syncthreads();
+    upq_levels<WG>(layers, sh, log_leaf, levels, active);
 }
 
 // Column-free levels log_child-1 .. log_stop of the tree, a few fused launches instead of one launch per level.
@@ -872,6 +902,25 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
     // layers below 2^up_log nodes are latency-bound: fused multi-level launches (k_merkle_upq) instead of one per level
     static const int up_log = getenv("TSTWO_MERKLE_UP_LOG") ? atoi(getenv("TSTWO_MERKLE_UP_LOG"))
                               : (getenv("TSTWO_MERKLE_UP_ONELANE") ? 15 : 16);
+    // a tree of exactly 4 equally long columns with at most 2^up_log rows (every FRI layer but the first few): leaves and the
+    // first 7 (or all, below 2^10 rows) levels in one launch
+    if (n_cols == 4 && max_log >= 1 && (int)max_log <= up_log && log_sizes[0] == max_log && log_sizes[1] == max_log && log_sizes[2] == max_log &&
+        log_sizes[3] == max_log && !getenv("TSTWO_MERKLE_NO_FUSED_LEAF4")) {
+        Context &c = ctx();
+        u32 log_child = max_log;
+        if (max_log <= 9) {
+            hipLaunchKernelGGL(k_merkle_leaf4_upq<1024>, dim3(1), dim3(1024), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, max_log);
+            log_child = 0;
+        } else {
+            hipLaunchKernelGGL(k_merkle_leaf4_upq<256>, dim3(1u << (max_log - 7)), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, 7u);
+            log_child = max_log - 7;
+        }
+        TSTWO_LAUNCH_CHECK();
+        int rc = log_child ? commit_upper_levels(layers, log_child, 0) : TSTWO_OK;
+        if (rc) return rc;
+        if (root) return small_d2h(root, layers, 32);
+        return TSTWO_OK;
+    }
     static const int sub_levels = [] { const char *e = getenv("TSTWO_MERKLE_SUBTREE"); int v = e ? atoi(e) : 2; return v > 4 ? 4 : v; }();   // measured: 2 (0.308 ms) < off (0.313) < 3 (0.326) < 4 (0.332) for 32 x 2^22
     const u32 **lc = n_cols ? new const u32 *[n_cols] : nullptr;
     const uint8_t *prev = nullptr;
