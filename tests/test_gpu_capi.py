@@ -440,7 +440,9 @@ def test_merkle_golden(golden):
     assert [[bytes(h).hex() for h in l] for l in layers] == e["layers"]
 
 
-@pytest.mark.parametrize("n_cols,log", [(1, 10), (4, 12), (15, 9), (16, 9), (17, 9), (32, 11), (48, 8), (256, 6), (300, 5), (600, 4)])
+@pytest.mark.parametrize("n_cols,log", [(1, 10), (4, 12), (15, 9), (16, 9), (17, 9), (32, 11), (48, 8), (256, 6), (300, 5), (600, 4),
+                                        # 4 equal columns: the fused leaf + quad-level kernels and their size boundaries (9 | 10, 16 | 17)
+                                        (4, 1), (4, 2), (4, 3), (4, 6), (4, 9), (4, 10), (4, 11), (4, 16), (4, 17)])
 def test_merkle_vs_oracle(n_cols, log):
     cols = [rand_column(600 + c, 1 << log) for c in range(n_cols)]
     layers, root = merkle_commit(cols, [log] * n_cols)
