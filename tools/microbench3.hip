@@ -122,21 +122,29 @@ KERNEL(k_blake_run_prio, P_LO R8(I_ADD) R8(I_XOR) P_HI R8(I_ALIGN) P_LO R8(I_ADD
 #define BF_PLAIN BF4(S_MAD) BF4(S_LSHR) BF4(S_ADDH) BF4(S_SUBP) BF4(S_MINM) BF4(S_APM) BF4(S_AMM) BF4(S_APMP) BF4(S_MINA) BF4(S_AMMP) BF4(S_MINB)
 // reordered so that the two final mins are adjacent: mad | lshr add sub | min | add sub sub add | min min
 #define BF_PRIO P_HI BF4(S_MAD) P_LO BF4(S_LSHR) BF4(S_ADDH) BF4(S_SUBP) P_HI BF4(S_MINM) P_LO BF4(S_APM) BF4(S_AMM) BF4(S_APMP) P_HI BF4(S_MINA) P_LO BF4(S_AMMP) P_HI BF4(S_MINB)
+// variant with a better port balance: a + m - P as ONE v_add3_u32 (heavy; -P in a VGPR) instead of a light v_sub after the
+// light v_add — 6 light + 5 heavy instead of 7 + 4, same count
+#define S_APMP3(a, b, lo, hi) "v_add3_u32 " b ", " a ", " b ", %10\n"
+#define BF4X(OP) OP("%0", "%4", "200", "201", "208") OP("%1", "%5", "202", "203", "209") OP("%2", "%6", "204", "205", "210") OP("%3", "%7", "206", "207", "211")
+#define S_AMMP3(a, b, lo, hi, x) "v_add_u32 v" x ", v" hi ", %8\n"
+#define S_MINB3(a, b, lo, hi, x) "v_min_u32 " b ", v" hi ", v" x "\n"
+#define BF_PRIO65 P_HI BF4(S_MAD) P_LO BF4(S_LSHR) BF4(S_ADDH) BF4(S_SUBP) P_HI BF4(S_MINM) P_LO BF4(S_APM) BF4(S_AMM) BF4X(S_AMMP3) P_HI BF4(S_APMP3) BF4(S_MINA) BF4X(S_MINB3)
 #define BF_KERNEL(NAME, ROUND)                                                                               \
     __global__ void __launch_bounds__(256) NAME(u32 *out, u32 seed) {                                        \
         u32 a0 = (threadIdx.x + seed) & 0x3fffffffu, a1 = (a0 * 3) & 0x3fffffffu, a2 = (a0 * 5) & 0x3fffffffu, a3 = (a0 * 7) & 0x3fffffffu; \
         u32 b0 = (a0 + 11) & 0x3fffffffu, b1 = (a0 + 13) & 0x3fffffffu, b2 = (a0 + 17) & 0x3fffffffu, b3 = (a0 + 19) & 0x3fffffffu; \
-        u32 P = 2147483647u;                                                                                 \
+        u32 P = 2147483647u, negP = 0x80000001u;                                                             \
         u32 t2 = ((seed * 2654435761u) % 2147483647u) * 2;                                                   \
         _Pragma("unroll 1") for (int i = 0; i < ITERS; i++) {                                                \
             asm volatile(ROUND ROUND ROUND ROUND ROUND ROUND "s_nop 0\n" "s_nop 0\n"                           \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)    \
-                         : "v"(P), "s"(t2) : "vcc", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207"); \
+                         : "v"(P), "s"(t2), "v"(negP) : "vcc", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211"); \
         }                                                                                                    \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ b0 ^ b1 ^ b2 ^ b3;                 \
     }
 BF_KERNEL(k_bf_plain, BF_PLAIN)      // 6 rounds x 4 butterflies x 11 = 264 VALU instructions per iteration
 BF_KERNEL(k_bf_prio, BF_PRIO)
+BF_KERNEL(k_bf_prio65, BF_PRIO65)
 
 typedef void (*kern_t)(u32 *, u32);
 struct Entry { const char *name; kern_t k; double n; };
@@ -166,7 +174,7 @@ int main(int argc, char **argv) {
     if (hipMalloc(&out, (size_t)cus * 8 * 256 * 4) != hipSuccess) return 1;
     Entry es[] = {{"runs of 8, prio: slow=3 fast=0", k_run8_prio, 64}, {"runs of 8, prio inverted", k_run8_prio_inv, 64}, {"runs of 4, prio", k_run4_prio, 64},
                   {"runs of 32, prio", k_run32_prio, 64}, {"24 fast / 8 min, prio", k_run24_8_prio, 64}, {"blake-like, prio", k_blake_run_prio, 64},
-                  {"butterfly asm 4-way plain (per instruction)", k_bf_plain, 264}, {"butterfly asm 4-way prio (per instruction)", k_bf_prio, 264},
+                  {"butterfly asm 4-way plain (per instruction)", k_bf_plain, 264}, {"butterfly asm 4-way prio (per instruction)", k_bf_prio, 264}, {"butterfly 6 light + 5 heavy (v_add3), prio", k_bf_prio65, 264},
                   {"add", k_add}, {"min", k_min}, {"add,xor alternating (same src1)", k_add_xor}, {"add,add alternating src1", k_add_addc},
                   {"add,lshr alternating", k_add_lshr}, {"add,min alternating same src1", k_add_min}, {"add,min alternating other src1", k_add_minc},
                   {"runs of 8 add / 8 min", k_run8}, {"runs of 16", k_run16}, {"runs of 32", k_run32}, {"24 fast (add,xor,lshr) / 8 min", k_run24_8},
