@@ -59,9 +59,12 @@ int tstwo_free(void *dev);                   /* returns the block to the library
 int tstwo_trim(void);                        /* synchronises and gives every cached block back to HIP */
 /* Where tstwo_malloc gets its blocks.  POOL (default): size-class free lists over hipMalloc, reuse ordered on the
  * library's stream.  DIRECT: hipMalloc / hipFree per call (free synchronises).  ASYNC: HIP's stream-ordered pool
- * (hipMallocAsync / hipFreeAsync on the library's stream).  OR in POISON to have every block handed out filled with
- * 0xA5 bytes first (debugging aid: reads of memory the library never wrote stop looking right by accident).
- * Environment, read at the first tstwo_malloc: TSTWO_ALLOC=pool|direct|async, TSTWO_POISON=1. */
+ * (hipMallocAsync / hipFreeAsync on the library's stream) — UNSAFE: on ROCm 7.2 / gfx950 that pool silently returns wrong
+ * data from the second or third allocate / compute / free cycle on (reproduced without any code of this library,
+ * tools/repro_hipmallocasync.hip), so tstwo_set_alloc_mode(ASYNC) and TSTWO_ALLOC=async FAIL with TSTWO_ERR_BAD_ARG unless
+ * the environment holds TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC=1 (for re-checking a newer runtime).  OR in POISON to have every
+ * block handed out filled with 0xA5 bytes first (debugging aid: reads of memory the library never wrote stop looking right
+ * by accident).  Environment, read at the first tstwo_malloc: TSTWO_ALLOC=pool|direct|async, TSTWO_POISON=1. */
 #define TSTWO_ALLOC_POOL 0
 #define TSTWO_ALLOC_DIRECT 1
 #define TSTWO_ALLOC_ASYNC 2
@@ -77,7 +80,8 @@ int tstwo_zero(void *dev, size_t bytes);                                  /* asy
  * channel).  Between begin and end every asynchronous entry point is RECORDED on the library's stream instead of executed;
  * tstwo_graph_launch replays the recorded sequence with one call.  Rules while capturing: no entry point that returns data
  * to the host (they synchronise) and none that uploads a host array (column tables beyond 64 pointers, gather requests,
- * quotient constants: the staging slot they travel through is only valid at capture time); allocations must hit the
+ * quotient constants: the staging slot they travel through is only valid at capture time — such a call fails with
+ * TSTWO_ERR_BAD_ARG "host-array upload during graph capture" and records nothing); allocations must hit the
  * library's caching allocator (run the sequence once eagerly first); all buffers the sequence uses must outlive the
  * graph, which addresses them by value. */
 int tstwo_graph_begin_capture(void);

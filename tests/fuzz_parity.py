@@ -327,6 +327,9 @@ def case_merkle_big():
     return f"merkle_big {len(logs)} cols max log {mx}"
 
 
+N_GENERATORS, N_GENERATORS_BIG = 10, 2        # round-robin: that many cases = every generator ran once
+
+
 def run(seconds=60.0, seed=0, big=False, max_cases=None, verbose=True):
     """Round-robin over the case generators until `seconds` have passed or `max_cases` ran; returns the number of cases."""
     global rng
@@ -335,8 +338,10 @@ def run(seconds=60.0, seed=0, big=False, max_cases=None, verbose=True):
     L.init(0)
     cases = [case_cfft, case_extended, case_merkle, case_fold, case_fields, case_fri, case_pcs, case_quotients, case_eval_decommit_qm31,
              case_rows_sharded]
+    assert len(cases) == N_GENERATORS
     if big:
         cases = [case_cfft_big, case_merkle_big]
+        assert len(cases) == N_GENERATORS_BIG
     t0, done = time.time(), 0
     while time.time() - t0 < seconds and (max_cases is None or done < max_cases):
         msg = cases[done % len(cases)]()

@@ -103,6 +103,21 @@ def test_no_cpu_fallback_without_gpu():
         T.HipColumn([1, 2, 3])
 
 
+def test_missing_rccl_is_an_error_not_a_crash():
+    """TSTWO_RCCL_LIB pointing nowhere: tstwo_comm_unique_id must return TSTWO_ERR_COMM with a message (round 2's code built
+    the message from two dlerror() calls, the second of which returns NULL -> std::string(NULL) -> SIGSEGV)."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from tstwo_amd import _lib as L\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "rc = L.lib().tstwo_comm_unique_id(buf)\n"
+            "print(rc, L.lib().tstwo_last_error().decode())\n" % ROOT)
+    env = dict(os.environ, TSTWO_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == 9 and "RCCL is not available" in msg and "/nonexistent/librccl.so.1" in msg
+
+
 def test_product_never_imports_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "tstwo_amd")):
         for f in files:

@@ -788,3 +788,44 @@ def test_allocator_modes_and_threads():
         t.join()
     assert not errors, errors
     L.call("tstwo_set_alloc_mode", L.ALLOC_POOL)
+
+
+def test_async_alloc_mode_is_refused_by_default():
+    """HIP's stream-ordered pool returns wrong data on ROCm 7.2 / gfx950 (profiles/r02_hipmallocasync_fault.txt): the mode must be
+    refused unless TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC=1 opts in."""
+    import os
+    if os.environ.get("TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC"):
+        pytest.skip("the opt-in is set")
+    with pytest.raises(L.TstwoError, match="TSTWO_ALLOC_ASYNC refused"):
+        L.call("tstwo_set_alloc_mode", L.ALLOC_ASYNC)
+    with pytest.raises(L.TstwoError, match="TSTWO_ALLOC_ASYNC refused"):
+        L.call("tstwo_set_alloc_mode", L.ALLOC_ASYNC | L.ALLOC_POISON)
+    b = L.DeviceBuffer(4096)          # the allocator still works in its previous mode
+    b.free()
+
+
+def test_host_array_upload_during_graph_capture_is_refused():
+    """A transform of more than 64 columns uploads its pointer table from a host array; recorded into a graph, the copy would read
+    a recycled staging slot at replay.  The call must fail and leave the table cache untouched: the same call works eagerly
+    afterwards and gives the oracle's evaluations."""
+    evs_host = [rand_column(990 + i, 1 << 13) for i in range(70)]
+    evs = [dev(e) for e in evs_host]
+    tw = dev_empty(1 << 12)
+    L.call("tstwo_twiddles_build", half_odds(12), 12, vp(tw), vp(None))
+    L.sync()
+    L.call("tstwo_graph_begin_capture")
+    try:
+        with pytest.raises(L.TstwoError, match="host-array upload during graph capture"):
+            L.call("tstwo_cfft_evaluate", ptrs(evs), len(evs), 13, half_odds(12), vp(tw), 12)
+    finally:
+        h = C.c_void_p()
+        try:
+            L.call("tstwo_graph_end_capture", C.byref(h))
+        except L.TstwoError:
+            pass
+        if h.value:
+            L.call("tstwo_graph_destroy", h)
+    otw = orc.precompute_twiddles(half_odds(12), 12)[0]
+    L.call("tstwo_cfft_evaluate", ptrs(evs), len(evs), 13, half_odds(12), vp(tw), 12)
+    for i in (0, 1, 69):
+        assert (host(evs[i], 1 << 13) == orc.cfft_evaluate(evs_host[i], 13, half_odds(12), otw, 12)).all()

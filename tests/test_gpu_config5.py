@@ -11,7 +11,7 @@ reverse order (another root; the oracle only re-hashes).
 HIP's own stream-ordered pool (TSTWO_ALLOC_ASYNC) is NOT in the default list: with it this very test fails
 deterministically on ROCm 7.2 / gfx950 from the second pass on, and so does tools/repro_hipmallocasync.hip — the same
 allocation / upload / kernel / free sequence with three trivial kernels and no code of this library (evidence:
-profiles/r02_hipmallocasync_fault.txt).  TSTWO_TEST_ASYNC_ALLOC=1 adds the two async modes back, to
+profiles/r02_hipmallocasync_fault.txt).  TSTWO_TEST_ASYNC_ALLOC=1 (together with TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC=1, without which the library refuses the mode) adds the two async modes back, to
 re-check on a newer runtime.
 The oracle side is the threaded driver of oracle/tstwo_oracle_mt.c (same scalar C functions, one column per task).
 """

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "libtstwo_hip.so")
 SOURCES = ["context.hip", "field_ops.hip", "cfft.hip", "fri.hip", "merkle.hip", "quotients.hip", "comm.hip"]
-HEADERS = ["common.h", "m31.cuh", "host_field.h", "cfft_fast.cuh", os.path.join("..", "..", "include", "tstwo_hip.h")]
+# every header under csrc/ (globbed: a new .cuh / .h marks all objects stale without having to be listed) + the public one
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))) + [os.path.join("..", "..", "include", "tstwo_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -606,7 +606,7 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
         if (e2 && atoi(e2) >= 1 && atoi(e2) <= 10) ka_max = (u32)atoi(e2);
     }
     u32 logta = kLogTileA;
-    if (n >= kMaxLogTileB && !getenv("TSTWO_CFFT_KB") && !getenv("TSTWO_CFFT_KA")) {
+    if (n >= kLogTileA && !getenv("TSTWO_CFFT_KB") && !getenv("TSTWO_CFFT_KA")) {     // n = 13 is one bottom pass whatever the column count
         // Few columns: the default tiles (2^13 contiguous, 2^14 strided) give 2^(n-13) x cols and 2^(n-14) x cols workgroups;
         // below ~2 per CU pick the split with the most workgroups in its emptier pass (ties: the larger tiles).
         // n = 20, one column: 12 + 8 layers on 2^12-word tiles = 256 + 256 workgroups instead of 128 + 64.

@@ -46,14 +46,22 @@ int ensure_comm_stream() {
 
 int load_rccl() {
     if (g_rccl.handle) return TSTWO_OK;
-    const char *names[] = {getenv("TSTWO_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // TSTWO_RCCL_LIB, when set, is the ONLY candidate (an explicit path that does not load is an error, not a hint)
+    const char *forced = getenv("TSTWO_RCCL_LIB");
+    const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char *names[3] = {nullptr, nullptr, nullptr};
+    if (forced && *forced) names[0] = forced;
+    else for (int i = 0; i < 3; i++) names[i] = defaults[i];
     void *h = nullptr;
     for (const char *n : names)      // a copy already mapped by the process (PyTorch's) first
         if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
     for (const char *n : names)
         if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);       // private: symbols are taken with dlsym only
-    if (!h) return set_error(TSTWO_ERR_COMM, std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so not found") +
-                                                 " (set TSTWO_RCCL_LIB to its path)");
+    if (!h) {
+        const char *e = dlerror();            // ONE call: dlerror() clears the state it returns
+        return set_error(TSTWO_ERR_COMM, std::string("RCCL is not available: ") + (e ? e : "librccl.so not found") +
+                                             " (set TSTWO_RCCL_LIB to its path)");
+    }
     Rccl r;
     r.handle = h;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");

@@ -63,9 +63,21 @@ int small_d2h(void *host_dst, const void *dev_src, size_t bytes) {
     memcpy(host_dst, c.pinned, bytes);
     return TSTWO_OK;
 }
+// A host-array upload cannot be part of a captured graph: the memcpy node would read a ring slot (or the caller's array) at
+// REPLAY time, long after it has been overwritten, and the slot's event would become a captured event.  Fail loudly instead
+// (include/tstwo_hip.h, "Rules while capturing").
+static int refuse_if_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return TSTWO_OK; }
+    if (st != hipStreamCaptureStatusNone)
+        return set_error(TSTWO_ERR_BAD_ARG, "host-array upload during graph capture (column tables beyond 64 pointers, gather "
+                                            "requests and quotient constants cannot be recorded)");
+    return TSTWO_OK;
+}
 int small_h2d(void *dev_dst, const void *host_src, size_t bytes) {
     Context &c = g_ctx;
     if (bytes == 0) return TSTWO_OK;
+    if (int rc = refuse_if_capturing(c.stream)) return rc;
     if (!c.up_ring || bytes > kUpSlotBytes) {
         TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.stream));
         TSTWO_HIP(hipStreamSynchronize(c.stream));
@@ -164,20 +176,31 @@ size_t size_class(size_t bytes) {
     if (bytes <= (p >> 1) + (p >> 2)) return (p >> 1) + (p >> 2);   // ... or 1.5 * 2^(k-1): at most 33 % slack
     return p;
 }
-void probe_env() {          // TSTWO_ALLOC=pool|direct|async, TSTWO_NO_POOL=1 (= direct), TSTWO_POISON=1
-    if (g_pool.probed) return;
-    g_pool.probed = true;
+// ASYNC (HIP's stream-ordered pool) is KNOWN TO RETURN WRONG DATA on ROCm 7.2 / gfx950: from the second or third pass of an
+// allocate / transform / free cycle on, kernels access other memory than the copy engines, with either release threshold
+// (profiles/r02_hipmallocasync_fault.txt: "[keep] 4 of 5 passes wrong"; tools/repro_hipmallocasync.hip reproduces it with no
+// code of this library).  The mode is therefore refused unless TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC=1 opts in (re-checks on a
+// newer runtime).
+bool async_alloc_allowed() {
+    const char *a = getenv("TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC");
+    return a && *a && strcmp(a, "0") != 0;
+}
+const char *kAsyncRefused = "TSTWO_ALLOC_ASYNC refused: hipMallocAsync's pool returns wrong data on ROCm 7.2 / gfx950 "
+                            "(set TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC=1 to force it)";
+int probe_env() {           // TSTWO_ALLOC=pool|direct|async, TSTWO_NO_POOL=1 (= direct), TSTWO_POISON=1
+    if (g_pool.probed) return TSTWO_OK;
     const char *m = getenv("TSTWO_ALLOC");
+    if (m && !strcmp(m, "async") && !async_alloc_allowed()) return set_error(TSTWO_ERR_BAD_ARG, kAsyncRefused);
+    g_pool.probed = true;
     if (m && !strcmp(m, "direct")) g_pool.mode = TSTWO_ALLOC_DIRECT;
     else if (m && !strcmp(m, "async")) g_pool.mode = TSTWO_ALLOC_ASYNC;
     else if (getenv("TSTWO_NO_POOL")) g_pool.mode = TSTWO_ALLOC_DIRECT;
     const char *p = getenv("TSTWO_POISON");
     g_pool.poison = p && *p && strcmp(p, "0") != 0;
+    return TSTWO_OK;
 }
-// HIP's stream-ordered pool: keep freed blocks mapped (release threshold = max) unless TSTWO_ASYNC_RELEASE=1 asks for HIP's
-// default (threshold 0: every synchronisation unmaps the free blocks and the next hipMallocAsync maps the range again).
-// With the default, kernels launched after such a re-map were observed to access other memory than the copy engines
-// (tools/diag_async_alloc.py): columns read back as uploaded, untouched by the transform that "ran" on them.
+// HIP's stream-ordered pool (opt-in only, see above): freed blocks stay mapped (release threshold = max) unless
+// TSTWO_ASYNC_RELEASE=1 asks for HIP's default (threshold 0).  NEITHER setting avoids the fault described above.
 int configure_async_pool() {
     hipMemPool_t pool = nullptr;
     TSTWO_HIP(hipDeviceGetDefaultMemPool(&pool, g_ctx.device));
@@ -365,6 +388,7 @@ int tstwo_set_alloc_mode(int mode) {
     const int base = mode & 0xF;
     if (base != TSTWO_ALLOC_POOL && base != TSTWO_ALLOC_DIRECT && base != TSTWO_ALLOC_ASYNC)
         return set_error(TSTWO_ERR_BAD_ARG, "tstwo_set_alloc_mode: unknown mode");
+    if (base == TSTWO_ALLOC_ASYNC && !async_alloc_allowed()) return set_error(TSTWO_ERR_BAD_ARG, kAsyncRefused);
     std::lock_guard<std::mutex> lock(g_pool.mu);
     g_pool.probed = true;
     int rc = trim_locked();            // cached blocks go back to HIP; live blocks remember the mode they came from
@@ -381,7 +405,7 @@ int tstwo_malloc(void **dev, size_t bytes) {
     *dev = nullptr;
     std::lock_guard<std::mutex> lock(g_pool.mu);
     if (!g_pool.probed) {
-        probe_env();
+        if (int rc_env = probe_env()) return rc_env;
         if (g_pool.mode == TSTWO_ALLOC_ASYNC) { int rc_cfg = configure_async_pool(); if (rc_cfg) return rc_cfg; }
     }
     if (bytes == 0) bytes = 16;
