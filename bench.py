@@ -5,20 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json config 5, column-sharded; weak scaling): every rank owns 32 trace columns
-of 2^22 M31 words (256 columns at 8 GPUs).  One step = PolyOps.evaluate (Circle FFT) of the rank's
-32 columns on CanonicCoset(22).circleDomain(), then MerkleProver.commit (Blake2s) over them, then
-an all-gather of the ranks' 32-byte Merkle roots (RCCL; N > 1 only).  Inputs are synthetic
-(SplitMix64 seeds 100+c) and resident in HBM before the timed region; twiddles are prebuilt.
-The transform is data-oblivious, so each step re-evaluates the previous step's output in place
-(uniform canonical M31 columns again) — no work is skipped or cached.
-Order of a run: one step on the fresh input (its Merkle root is kept and compared with the CPU oracle's -> `root_match`),
---spinup untimed steps (default 80: the part needs ~50 ms of load before its clocks settle; `spinup_steps` in the line),
-W - 1 more warm-up steps, barrier, K timed steps, barrier.
+Workload = BASELINE.json config 5 as SURVEY.md §8(d) defines it: a FIXED trace of 256 columns x 2^22 M31 words, column-sharded
+(strong scaling): rank g of N owns columns shard_columns(256, N, g) — all 256 at N = 1, 128 / 64 / 32 at N = 2 / 4 / 8 — and
+commits them as 32-column Merkle trees, i.e. 8 trees in all whatever N is: the 8 roots (stwo's TreeVec, one
+CommitmentTreeProver per tree, pcs/prover.ts:62-64,209-237) do not depend on the GPU count.  One step = PolyOps.evaluate
+(Circle FFT) of the rank's columns on CanonicCoset(22).circleDomain() in ONE call, MerkleProver.commit (Blake2s) per tree,
+then (N > 1) an all-gather of the ranks' 8/N roots of 32 bytes (RCCL, through the C ABI).  `--scaling weak` keeps round 2's
+mode instead (32 columns = one tree per GPU, 32 N columns in all).  Inputs are synthetic (SplitMix64 seeds 100+c) and
+resident in HBM before the timed region; twiddles are prebuilt.  The transform is data-oblivious, so each step re-evaluates
+the previous step's output in place (uniform canonical M31 columns again) — no work is skipped or cached.
+
+Order of a run (rank 0, N = 1: first a child process `rocprofv3 --pmc ... -- python tools/pmc_target.py` collects the HBM
+counters of the same launches -> roofline.traffic): one step on the fresh input (its 8/N roots are kept and compared with the
+CPU oracle's -> `root_match`), W - 1 more warm-up steps, barrier, K timed steps from idle clocks (`ms_per_step_cold`: what a
+prover that commits a handful of trees sees), spin-up steps until the part has been under load for --spinup-ms (its clocks
+need 40-75 ms to settle; `spinup_steps` in the line), barrier, K timed steps (`ms_per_step`, `value`), barrier.
 
 Rank 0 prints ONE JSON line:  value = (all ranks' columns * 2^22 elements * K) / max-over-ranks time.
-`roofline` prices the dominant kernel (the CFFT pass kernel) against the 8 TB/s HBM roofline with the
-algorithmic bytes of SURVEY.md §8(d); `cpu_baseline` times the CPU oracle on a bounded sample.
+`roofline` prices the dominant kernel (the CFFT pass kernels) against the 8 TB/s HBM roofline with the
+algorithmic bytes of SURVEY.md §8(d); `cpu_baseline` times the CPU oracle on the same step.
 """
 from __future__ import annotations
 
@@ -26,7 +31,10 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,16 +43,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_SIZE = 22
-COLS_PER_GPU = 32
+TOTAL_COLS = 256                # the fixed trace of BASELINE config 5
+TREE_COLS = 32                  # columns per Merkle tree (8 trees = stwo's TreeVec of config 5)
 VALU_PER_BUTTERFLY = 11.6      # measured: (113.7M + 153.6M wave instr) * 64 / (32 cols * 22 layers * 2^21), profiles/r02_sq_counters.json
 VALU_PEAK = 256 * 4 * 16 * 2.4e9          # nominal: one wave64 VALU instruction per SIMD per 4 cycles at 2.4 GHz
 VALU_PEAK_MEASURED = 35.3e12              # what ONE VALU issue port sustains (one instruction per ~4.4 nominal cycles per SIMD):
                                           # tools/microbench2.hip, profiles/r02_microbench.json
 VALU_PEAK_DUAL_MEASURED = 60.3e12         # the butterfly's 11 instructions issued in priority phases (second port takes the light
                                           # VOP2s): 2.61 nominal cycles each, tools/microbench3.hip, profiles/r02_microbench3.json
-SPINUP_STEPS = 80                         # untimed steps before the W warm-up steps: the part needs ~40-75 ms of load before its
-                                          # clocks settle (tools/cfft_time.py --series: 560 -> 487 us per transform), and W = 5
-                                          # steps are 5 ms
+SPINUP_MS = 200.0                         # load the part must have seen before the headline timed region: it needs ~40-75 ms
+                                          # before its clocks settle (tools/cfft_time.py --series: 560 -> 487 us per transform)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -58,17 +66,38 @@ def splitmix_column(seed: int, n: int) -> np.ndarray:
     with np.errstate(over="ignore"):
         while filled < n:
             m = n - filled + 64
-            s = state + gamma * np.arange(1, m + 1, dtype=np.uint64)
-            state = s[-1]
-            z = s
-            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-            z = z ^ (z >> np.uint64(31))
-            v = (z >> np.uint64(33)).astype(np.uint32)
+            z = np.arange(1, m + 1, dtype=np.uint64)
+            z *= gamma
+            z += state
+            state = z[-1].copy()
+            t = z >> np.uint64(30)
+            z ^= t
+            z *= np.uint64(0xBF58476D1CE4E5B9)
+            np.right_shift(z, np.uint64(27), out=t)
+            z ^= t
+            z *= np.uint64(0x94D049BB133111EB)
+            np.right_shift(z, np.uint64(31), out=t)
+            z ^= t
+            z >>= np.uint64(33)
+            v = z.astype(np.uint32)
             v = v[v < P][: n - filled]
             out[filled:filled + v.size] = v
             filled += v.size
     return out
+
+
+def host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def splitmix_columns(seeds, n: int) -> list:
+    """The same columns, generated on a few host threads (numpy releases the GIL): 256 columns x 2^22 take ~0.4 s each on one."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(16, host_cores()))) as ex:
+        return list(ex.map(lambda sd: splitmix_column(sd, n), seeds))
 
 
 def cpu_oracle():
@@ -78,53 +107,87 @@ def cpu_oracle():
     return orc
 
 
-def cpu_baseline(sample_cols: int, threads: int = 0):
-    """CPU oracle (oracle/, kind "port": -O3 scalar C) timed beside the GPU step on a bounded sample:
-      * one thread: `sample_cols` of the 32 columns — CFFT evaluate + Merkle commit over them;
-      * all host cores (reported as cpu_baseline.value): the FULL 32-column step on C threads (oracle/tstwo_oracle_mt.c:
-        one column per task for the CFFT, the leaf range cut into contiguous shards for the Merkle tree, whose root equals
-        the single-tree root) — `threads` = every core the process may run on unless given.
-    Returns the record and the oracle's root of the step's input, which main() compares with the GPU's."""
+def cpu_baseline(cols_host: list, n: int, tree_cols: int, single_cols: int, threads: int = 0):
+    """CPU oracle (oracle/, kind "port": -O3 scalar C) timed beside the GPU step:
+      * one thread: `single_cols` of the columns — CFFT evaluate + Merkle commit over them;
+      * all host cores (reported as cpu_baseline.value): the FULL step of rank 0 at N = 1 — every column of the trace — on C
+        threads (oracle/tstwo_oracle_mt.c: one column per task for the CFFT; per tree the leaf range cut into contiguous
+        shards, whose root equals the single-tree root) — `threads` = every core the process may run on unless given.
+    `cols_host` (the step's input, host copies) is transformed IN PLACE.  Returns the record; its "roots" are the oracle's
+    roots of the step's trees, which main() compares with the GPU's."""
     orc = cpu_oracle()
-    n = LOG_SIZE
+    n_cols = len(cols_host)
     half = orc.lib().orc_half_odds_initial(n - 1)
     tw, _ = orc.precompute_twiddles(half, n - 1, inverse=False)       # untimed, like the GPU side
-    cols = [splitmix_column(100 + c, 1 << n) for c in range(sample_cols)]
     t0 = time.perf_counter()
-    evs = [orc.cfft_evaluate(c, n, half, tw, n - 1) for c in cols]
+    evs = [orc.cfft_evaluate(c, n, half, tw, n - 1) for c in cols_host[:single_cols]]      # copies
     t1 = time.perf_counter()
-    orc.merkle_commit(evs, [n] * sample_cols)
+    orc.merkle_commit(evs, [n] * single_cols)
     t2 = time.perf_counter()
     single = {
-        "value": sample_cols * (1 << n) / (t2 - t0), "unit": "elems/s", "cores": 1,
-        "sample": f"{sample_cols} of {COLS_PER_GPU} columns x 2^{n}: CFFT evaluate ({t1 - t0:.2f} s) + Merkle commit over them ({t2 - t1:.2f} s)",
-        "cfft_butterflies_per_s": sample_cols * n * (1 << (n - 1)) / (t1 - t0),
+        "value": single_cols * (1 << n) / (t2 - t0), "unit": "elems/s", "cores": 1,
+        "sample": f"{single_cols} of {n_cols} columns x 2^{n}: CFFT evaluate ({t1 - t0:.2f} s) + Merkle commit over them ({t2 - t1:.2f} s)",
+        "cfft_butterflies_per_s": single_cols * n * (1 << (n - 1)) / (t1 - t0),
     }
     del evs
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     if threads <= 0:
         threads = cores
-    all_cols = cols + [splitmix_column(100 + c, 1 << n) for c in range(sample_cols, COLS_PER_GPU)]
     t3 = time.perf_counter()
-    orc.mt_cfft_evaluate(all_cols, n, half, tw, n - 1, threads)       # in place
+    orc.mt_cfft_evaluate(cols_host, n, half, tw, n - 1, threads)       # in place
     t4 = time.perf_counter()
-    root = orc.mt_merkle_root(all_cols, n, threads)
+    roots = [orc.mt_merkle_root(cols_host[t:t + tree_cols], n, threads) for t in range(0, n_cols, tree_cols)]
     t5 = time.perf_counter()
     return {
-        "value": COLS_PER_GPU * (1 << n) / (t5 - t3),
+        "value": n_cols * (1 << n) / (t5 - t3),
         "unit": "elems/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"the full step ({COLS_PER_GPU} columns x 2^{n}) on {threads} C threads = every core this process may use "
-                  f"(os.cpu_count() = {os.cpu_count()}): column-parallel CFFT ({t4 - t3:.2f} s) + leaf-sharded Merkle commit "
-                  f"({t5 - t4:.2f} s); oracle built -O3",
-        "cfft_butterflies_per_s": COLS_PER_GPU * n * (1 << (n - 1)) / (t4 - t3),
-        "root": root.hex(),
+        "sample": f"the full step ({n_cols} columns x 2^{n}, {len(roots)} trees of {tree_cols} columns) on {threads} C threads = every core "
+                  f"this process may use (os.cpu_count() = {os.cpu_count()}): column-parallel CFFT ({t4 - t3:.2f} s) + leaf-sharded "
+                  f"Merkle commits ({t5 - t4:.2f} s); oracle built -O3",
+        "cfft_butterflies_per_s": n_cols * n * (1 << (n - 1)) / (t4 - t3),
+        "roots": [r.hex() for r in roots],
         "single_thread": single,
     }
+
+
+def pmc_traffic(n: int, n_cols: int, timeout_s: float = 240.0):
+    """HBM traffic of the CFFT pass kernels from the hardware counters, collected by THIS run: two fresh child processes
+    `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- <python> tools/pmc_target.py --cfft-only` (separate passes: the TCC block cannot hold
+    both; --pmc only, no trace domains; the interpreter itself after `--`, no shell / env / re-exec), summarised by
+    tools/pmc_summary.py (the guide's gfx950 corrections, calibrated on kernels with known byte counts in the same run).
+    Called before this process touches the GPU.  Returns (bytes per launch | None, source record)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, {"reason": "rocprofv3 not found"}
+    if any(k.startswith("ROCPROF") or k.startswith("ROCPROFILER") for k in os.environ):
+        return None, {"reason": "already running under a profiler"}
+    tmp = tempfile.mkdtemp(prefix="tstwo_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    target = os.path.join(ROOT, "tools", "pmc_target.py")
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--",
+                   sys.executable, target, "--cfft-only", "--cols", str(n_cols), "--log-size", str(n)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, {"reason": f"rocprofv3 --pmc {ctr} exited with {r.returncode}: {r.stdout.decode(errors='replace')[-300:]}"}
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_summary
+        pj = pmc_summary.summarise(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), n, n_cols)
+    except subprocess.TimeoutExpired:
+        return None, {"reason": f"rocprofv3 --pmc child exceeded {timeout_s:.0f} s"}
+    except Exception as e:      # noqa: BLE001 — a counter leg that fails must not take the measurement down with it
+        return None, {"reason": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    src = {"collector": "child rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_target.py --cfft-only (this run)",
+           "kernels": pj.get("cfft_kernels"), "per_kernel": pj.get("cfft_per_kernel"), "lib_sha16": pj.get("lib_sha16"),
+           "calibration_true_over_counter": pj.get("calibration_true_over_counter"),
+           "algorithmic_bytes_per_launch": pj.get("algorithmic_bytes_per_launch"), "seconds": round(time.perf_counter() - t0, 1)}
+    return pj.get("hbm_bytes_per_launch"), src
 
 
 def main():
@@ -132,26 +195,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spinup", type=int, default=SPINUP_STEPS, help="untimed clock spin-up steps before the warm-up steps")
-    ap.add_argument("--cols", type=int, default=COLS_PER_GPU, help="columns per GPU")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): the fixed 256-column trace of config 5 sharded over the GPUs; weak: 32 columns per GPU")
+    ap.add_argument("--total-cols", type=int, default=TOTAL_COLS, help="trace columns in all (strong scaling)")
+    ap.add_argument("--cols", type=int, default=TREE_COLS, help="columns per GPU (weak scaling)")
+    ap.add_argument("--tree-cols", type=int, default=TREE_COLS, help="columns per Merkle tree")
     ap.add_argument("--log-size", type=int, default=LOG_SIZE)
-    ap.add_argument("--cpu-cols", type=int, default=4, help="columns in the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--spinup-ms", type=float, default=SPINUP_MS, help="load (ms) the part must have seen before the headline timed region")
+    ap.add_argument("--cpu-cols", type=int, default=4, help="columns in the one-thread CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-4 (the `configs` list of the JSON line)")
-    ap.add_argument("--pmc-json", default=None, help="tools/pmc_summary.py output of a --pmc run of THIS command: fills roofline.traffic")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the child rocprofv3 --pmc passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-json", default=None, help="tools/pmc_summary.py output of an earlier --pmc run of THIS build, instead of the child passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n, n_cols = args.log_size, args.cols
+    n, tree_cols = args.log_size, args.tree_cols
     N = 1 << n
+    total_cols = args.total_cols if args.scaling == "strong" else args.cols * world
+    if total_cols % (world * tree_cols):
+        raise SystemExit(f"bench.py: {total_cols} columns do not split into {tree_cols}-column trees over {world} GPUs")
+
+    # ---- HBM counters of the launches this run times, from a child process, before this one touches the GPU (N = 1 only)
+    traffic, traffic_source = None, {"reason": "not collected (N > 1, --no-pmc or not rank 0)"}
+    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_json:
+        traffic, traffic_source = pmc_traffic(n, total_cols)
 
     # torch.distributed is control plane only (rendezvous, barrier, max-reduce of the elapsed time, hand-over of the RCCL
     # unique id) on the gloo backend; the one collective on the data path — the all-gather of Merkle roots — is RCCL
     # over xGMI issued through the library's own C ABI (tstwo_comm_init / tstwo_allgather_async), exactly what a Bun
     # host would call.  TSTWO_BENCH_COLLECTIVE=gloo rehearses the N > 1 control flow on a one-GPU box (all ranks share
     # GPU 0, where RCCL refuses several ranks per device): roots then travel through host memory.
+    # Nothing below initialises the GPU before the rendezvous (torch.cuda.device_count() does not).
     import torch
     import torch.distributed as dist
     n_dev = torch.cuda.device_count()
@@ -179,29 +256,40 @@ def main():
         L.call("tstwo_comm_init", rank, world, (C.c_uint8 * 128).from_buffer_copy(ids[0]))
     backend = HipBackend()
 
-    # ---- the rank's shard of the (world * n_cols) trace columns, resident in HBM
-    my_cols = shard_columns(world * n_cols, world, rank)
+    # ---- the rank's shard of the trace columns, resident in HBM; trees = consecutive groups of tree_cols of them
+    my_cols = shard_columns(total_cols, world, rank)
+    n_cols = len(my_cols)
+    n_trees = n_cols // tree_cols
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu
+    cols_host = splitmix_columns([100 + c for c in my_cols], N)
     dev_cols = []
-    for c in my_cols:
+    for h in cols_host:
         b = L.DeviceBuffer(4 * N)
-        b.upload(splitmix_column(100 + c, N))
+        b.upload(h)
         dev_cols.append(b)
+    if not want_cpu:
+        cols_host = None
     col_ptrs = L.ptr_array([b.ptr for b in dev_cols])
+    tree_ptrs = [L.ptr_array([b.ptr for b in dev_cols[t * tree_cols:(t + 1) * tree_cols]]) for t in range(n_trees)]
     half_initial = backend.canonic_half_coset_initial(n)
     tw = L.DeviceBuffer(4 * (N // 2))
     L.call("tstwo_twiddles_build", half_initial, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
-    layers = L.DeviceBuffer(32 * ((2 << n) - 1))
-    log_sizes = L.u32x([n] * n_cols)
-    # two root slots; the all-gather of step k runs on the library's collective stream and overlaps the CFFT of step k+1
+    layers = [L.DeviceBuffer(32 * ((2 << n) - 1)) for _ in range(n_trees)]
+    log_sizes = L.u32x([n] * tree_cols)
+    # two send/receive slots; the all-gather of step k runs on the library's collective stream and overlaps the CFFT of step k+1
     # (tstwo_comm_wait at the next issue point makes the main stream wait for it on the device, never the host)
-    root_slot = [L.DeviceBuffer(32) for _ in range(2)]
-    roots_all = [L.DeviceBuffer(32 * world) for _ in range(2)]
-    roots_host = [np.zeros(32 * world, dtype=np.uint8) for _ in range(2)]
+    rec = 32 * n_trees                                   # this rank's record: its trees' roots in TreeVec order
+    root_slot = [L.DeviceBuffer(rec) for _ in range(2)]
+    roots_all = [L.DeviceBuffer(rec * world) for _ in range(2)]
+    roots_host = [np.zeros(rec * world, dtype=np.uint8) for _ in range(2)]
     step_no = [0]
     L.sync()
 
     # HIP events on the library's stream, three per timed step, read after the timed region
     evs = [[L.Event() for _ in range(3)] for _ in range(args.steps)]
+
+    def my_roots() -> bytes:
+        return b"".join(bytes(l.download(np.uint8, 32).tobytes()) for l in layers)
 
     def step(ev):
         if ev:
@@ -209,7 +297,8 @@ def main():
         L.call("tstwo_cfft_evaluate", col_ptrs, n_cols, n, half_initial, C.c_void_p(tw.ptr), n - 1)
         if ev:
             ev[1].record()
-        L.call("tstwo_merkle_commit", col_ptrs, log_sizes, n_cols, C.c_void_p(layers.ptr), None)
+        for t in range(n_trees):
+            L.call("tstwo_merkle_commit", tree_ptrs[t], log_sizes, tree_cols, C.c_void_p(layers[t].ptr), None)
         if ev:
             ev[2].record()
         if use_dist:   # the only exchange on the path: 32-byte roots over RCCL/xGMI
@@ -217,10 +306,11 @@ def main():
             step_no[0] += 1
             if collective == "rccl":
                 L.call("tstwo_comm_wait")                  # the previous step's collective (it had this whole step to finish)
-                L.call("tstwo_copy", C.c_void_p(root_slot[k].ptr), C.c_void_p(layers.ptr), 32)
-                L.call("tstwo_allgather_async", C.c_void_p(root_slot[k].ptr), C.c_void_p(roots_all[k].ptr), 32)
+                for t in range(n_trees):
+                    L.call("tstwo_copy", C.c_void_p(root_slot[k].ptr + 32 * t), C.c_void_p(layers[t].ptr), 32)
+                L.call("tstwo_allgather_async", C.c_void_p(root_slot[k].ptr), C.c_void_p(roots_all[k].ptr), rec)
             else:                                           # rehearsal: host round trip + gloo
-                mine = torch.from_numpy(layers.download(np.uint8, 32).copy())
+                mine = torch.from_numpy(np.frombuffer(my_roots(), dtype=np.uint8).copy())
                 out = torch.from_numpy(roots_host[k])
                 dist.all_gather_into_tensor(out, mine)
 
@@ -240,38 +330,54 @@ def main():
         if n_dev:
             torch.cuda.synchronize()
 
-    # Correctness of the measured workload: the first (untimed) step runs on the fresh synthetic input; its root is
-    # compared below with the CPU oracle's root of the same 32 x 2^22 columns (cpu_baseline.root) -> "root_match".
+    def timed(k, events=None):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(events[i] if events else None)
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # Correctness of the measured workload: the first (untimed) step runs on the fresh synthetic input; its roots are
+    # compared below with the CPU oracle's roots of the same columns (cpu_baseline.roots) -> "root_match".
     step(None)
-    gpu_root_first = bytes(layers.download(np.uint8, 32).tobytes())
-    for _ in range(args.spinup):          # clock spin-up (not counted as warm-up; see SPINUP_STEPS)
-        step(None)
+    gpu_roots_first = my_roots()
     for _ in range(max(args.warmup - 1, 0)):
         step(None)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(evs[i])
-    barrier()
-    elapsed = time.perf_counter() - t0
+    cold = timed(args.steps)                       # K steps from idle clocks: reported as ms_per_step_cold
+    # spin-up: as many further steps as the remaining load time needs at the cold step time (`cold` is already the maximum over
+    # ranks, so every rank runs the same number of steps and of collectives)
+    need_ms = args.spinup_ms - cold * 1e3
+    spin = int(np.ceil(need_ms / (cold * 1e3 / args.steps))) if need_ms > 0 else 0
+    for _ in range(spin):
+        step(None)
+    elapsed = timed(args.steps, evs)               # the headline: EXACTLY K steps between two barriers, max over ranks
     t_cfft = sum(e[0].elapsed_ms(e[1]) for e in evs)
     t_merkle = sum(e[1].elapsed_ms(e[2]) for e in evs)
 
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # every rank's root must have arrived in rank order: compare the RCCL result with a gloo all-gather of the same roots
+        # every rank's roots must have arrived in rank order: compare the RCCL result with a gloo all-gather of the same roots
         last = (step_no[0] - 1) & 1
-        got = roots_all[last].download(np.uint8, 32 * world) if collective == "rccl" else roots_host[last]
-        mine = torch.from_numpy(layers.download(np.uint8, 32).copy())
-        ref = torch.zeros(32 * world, dtype=torch.uint8)
+        got = roots_all[last].download(np.uint8, rec * world) if collective == "rccl" else roots_host[last]
+        mine = torch.from_numpy(np.frombuffer(my_roots(), dtype=np.uint8).copy())
+        ref = torch.zeros(rec * world, dtype=torch.uint8)
         dist.all_gather_into_tensor(ref, mine)
         assert bytes(got.tobytes()) == bytes(ref.numpy().tobytes()), "all-gathered roots differ from the ranks' own roots"
+        first = torch.from_numpy(np.frombuffer(gpu_roots_first, dtype=np.uint8).copy())
+        allfirst = torch.zeros(rec * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(allfirst, first)
+        tree_roots_first = bytes(allfirst.numpy().tobytes())
+    else:
+        tree_roots_first = gpu_roots_first
 
     if rank == 0:
         steps = args.steps
-        total_elems = world * n_cols * N * steps
+        total_elems = total_cols * N * steps
         cfft_ms = t_cfft / steps
         merkle_ms = t_merkle / steps
         # dominant kernel: the CFFT pass kernels (fast::k_cfft_a<INV,K>, fast::k_cfft_b<INV,LOGT>), (passes) launches per step over all columns.
@@ -280,19 +386,19 @@ def main():
         algo_bytes_launch = algo_bytes_transform / passes
         launch_ms = cfft_ms / passes
         achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9
-        merkle_bytes = (4.0 * n_cols + 64.0) * N                    # 4*C*N read + 64*N written
-        # HBM traffic is a PMC measurement of a separate rocprofv3 --pmc run of this same command; it enters the line only
-        # when that run's summary is handed in (tools/refresh_profiles.sh does), never from a stale committed file.
-        traffic, traffic_source = None, None
-        if args.pmc_json and os.path.exists(args.pmc_json):
+        merkle_bytes = (4.0 * tree_cols + 64.0) * N * n_trees       # per tree 4*C*N read + 64*N written
+        import hashlib
+        lib_now = hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
+        if args.pmc_json and os.path.exists(args.pmc_json):        # counters of an earlier run of this build, handed in
             pj = json.load(open(args.pmc_json))
             traffic = pj.get("hbm_bytes_per_launch")
-            import hashlib
-            lib_now = hashlib.sha256(open(L.LIB_PATH, "rb").read()).hexdigest()[:16]
             traffic_source = {"file": os.path.relpath(os.path.abspath(args.pmc_json), ROOT), "kernels": pj.get("cfft_kernels"),
-                              "lib_sha16": pj.get("lib_sha16"), "same_build": pj.get("lib_sha16") == lib_now}
-            if not traffic_source["same_build"]:
-                traffic = None          # counters of another build say nothing about this one
+                              "lib_sha16": pj.get("lib_sha16")}
+        if traffic is not None:
+            traffic_source["same_build"] = traffic_source.get("lib_sha16") == lib_now
+            if not traffic_source["same_build"] or traffic_source.get("algorithmic_bytes_per_launch", algo_bytes_launch) != algo_bytes_launch:
+                traffic = None          # counters of another build or another launch shape say nothing about this one
+        valu_rate = VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3)
         out = {
             "metric": "M31 CFFT elems/sec at log_size=22 (per step: CFFT evaluate + Blake2s Merkle commit + root all-gather)",
             "value": total_elems / elapsed,
@@ -300,17 +406,21 @@ def main():
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
-            "spinup_steps": args.spinup,
+            "spinup_steps": spin,
+            "cold_steps": steps,
             "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_cold": cold / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 5 shard: {n_cols} columns x 2^{n} per GPU "
-                                   f"({world * n_cols} columns total), CircleDomain of CanonicCoset({n}); "
-                                   "evaluate + per-GPU Merkle tree" + (" + RCCL all-gather of roots (C ABI: tstwo_allgather_async)" if world > 1 else ""),
-                       "log_size": n, "columns_per_gpu": n_cols, "parallelism": f"column-shard x{world}"},
+            "config": {"workload": f"BASELINE config 5: {total_cols} columns x 2^{n}, column-shard x{world} "
+                                   f"({n_cols} columns = {n_trees} trees of {tree_cols} per GPU; {total_cols // tree_cols} trees in all), "
+                                   f"CircleDomain of CanonicCoset({n}); evaluate in one call + one Merkle tree per {tree_cols} columns"
+                                   + (" + RCCL all-gather of the roots (C ABI: tstwo_allgather_async)" if world > 1 else ""),
+                       "log_size": n, "total_columns": total_cols, "columns_per_gpu": n_cols, "trees_per_gpu": n_trees,
+                       "columns_per_tree": tree_cols, "parallelism": f"column-shard x{world}"},
             "cfft_ms": cfft_ms,
             "cfft_butterflies_per_s": n_cols * n * (N // 2) / (cfft_ms * 1e-3),
             "cfft_elems_per_s": n_cols * N / (cfft_ms * 1e-3),
@@ -320,36 +430,37 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9,0,14> + fast::k_cfft_b<false,13,false> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": passes, "avg_launch_ms": launch_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch, "lib_sha16": lib_now,
                          # the lane-op rate is reported next to the HBM fraction.  11.3-12.2 VALU instructions
                          # per butterfly (profiles/r02_sq_counters.json); one issue port: nominal 39.3e12 lane-ops/s
                          # = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz, measured 35.3e12; with the second port taking the light
                          # VOP2s of another wave (priority phases) the same instruction mix peaks at 60.3e12.
                          "valu": {"instr_per_butterfly": VALU_PER_BUTTERFLY, "peak_lane_ops_per_s": VALU_PEAK,
-                                  "achieved_lane_ops_per_s": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3),
-                                  "frac": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK,
+                                  "achieved_lane_ops_per_s": valu_rate, "frac": valu_rate / VALU_PEAK,
                                   "measured_peak_lane_ops_per_s": VALU_PEAK_MEASURED,
-                                  "frac_of_measured_peak": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK_MEASURED,
+                                  "frac_of_measured_peak": valu_rate / VALU_PEAK_MEASURED,
                                   "dual_issue_peak_lane_ops_per_s": VALU_PEAK_DUAL_MEASURED,
-                                  "frac_of_dual_issue_peak": VALU_PER_BUTTERFLY * n_cols * n * (N // 2) / (cfft_ms * 1e-3) / VALU_PEAK_DUAL_MEASURED}},
+                                  "frac_of_dual_issue_peak": valu_rate / VALU_PEAK_DUAL_MEASURED}},
             "device": L.device_name(),
         }
         root_ok = None
-        if not args.no_cpu and args.cpu_cols > 0 and n == LOG_SIZE and n_cols == COLS_PER_GPU and world == 1:   # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_cols)
-            root_ok = out["cpu_baseline"]["root"] == gpu_root_first.hex()
+        if want_cpu:                                   # rank 0 at N = 1 only
+            del dev_cols[:], layers[:]
+            out["cpu_baseline"] = cpu_baseline(cols_host, n, tree_cols, min(args.cpu_cols, n_cols))
+            root_ok = "".join(out["cpu_baseline"]["roots"]) == tree_roots_first.hex()
+            cols_host = None
         else:
             out["cpu_baseline"] = None
-        out["gpu_root"] = gpu_root_first.hex()
-        out["root_match"] = root_ok            # GPU root of the first step == CPU oracle root of the same input (None: oracle leg not run)
+        out["gpu_roots"] = [tree_roots_first[32 * t:32 * t + 32].hex() for t in range(len(tree_roots_first) // 32)]
+        out["root_match"] = root_ok            # GPU roots of the first step == CPU oracle roots of the same input (None: oracle leg not run)
         if world == 1 and not args.no_configs:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from bench_configs import run_configs
-            del dev_cols[:]
+            del dev_cols[:], layers[:]
             out["configs"] = run_configs(reps=10, no_cpu=args.no_cpu)      # BASELINE configs 1-4, same JSON line
         print(json.dumps(out), flush=True)
         if root_ok is False:
-            raise SystemExit("bench.py: the GPU Merkle root of the 32 x 2^22 step differs from the CPU oracle's: the measured numbers are void")
+            raise SystemExit("bench.py: the GPU Merkle roots of the step differ from the CPU oracle's: the measured numbers are void")
 
     if use_dist:
         dist.barrier()

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic, applying the gfx950
-corrections of MI355X_MICROARCH.md §HBM after calibrating them on kernels with known byte counts."""
+corrections of MI355X_MICROARCH.md §HBM after calibrating them on kernels with known byte counts.
+
+    pmc_summary.py FETCH_DIR WRITE_DIR [log_size cols] > out.json        (bench.py calls summarise() directly)"""
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -18,8 +22,8 @@ def load(root, counter):
     return out
 
 
-def main():
-    fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+def summarise(fetch_dir, write_dir, log_size=22, cols=256):
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     ncal = (1 << 26) * 4.0
     res = {"unit": "bytes per launch", "kernels": {}}
     cal = {}
@@ -40,16 +44,17 @@ def main():
     cf = {k: d for k, d in res["kernels"].items() if "k_cfft" in k}
     if cf:
         res["hbm_bytes_per_launch"] = sum(d["hbm_bytes_corrected"] for d in cf.values()) / len(cf)   # avg over the transform's passes
-        res["algorithmic_bytes_per_launch"] = 8.0 * (1 << 22) * 32 / len(cf)
+        res["algorithmic_bytes_per_launch"] = 8.0 * (1 << log_size) * cols / len(cf)
         res["cfft_kernels"] = sorted(cf)
-    # which build these counters belong to (bench.py --pmc-json copies this next to roofline.traffic)
-    import hashlib
-    import os
+        res["cfft_per_kernel"] = {k: {"fetch": round(d["FETCH_SIZE_bytes_raw"] * k16), "write": round(d["WRITE_SIZE_bytes_raw"] * (cal.get("write_16B") or 1.0))}
+                                  for k, d in cf.items()}
+    # which build these counters belong to (bench.py puts this next to roofline.traffic)
     lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tstwo_amd", "libtstwo_hip.so")
     if os.path.exists(lib):
         res["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
-    print(json.dumps(res, indent=1))
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    extra = [int(x) for x in sys.argv[3:5]]
+    print(json.dumps(summarise(sys.argv[1], sys.argv[2], *extra), indent=1))

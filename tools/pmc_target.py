@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """Workload for the rocprofv3 --pmc passes: two calibration kernels with known byte counts (16-byte and 4-byte lane
-accesses), then the bench step (32 x 2^22 evaluate + Merkle commit) twice."""
+accesses), then the bench step (C x 2^n evaluate + one Merkle commit per 32 columns) twice, then eval_at_point.
+
+    pmc_target.py [--cols C] [--log-size n] [--cfft-only]
+
+--cfft-only (bench.py's own child passes): calibration + the evaluate call only.  The transform is data-oblivious, so the
+columns are device copies of one random column (no 4 GiB of host data to generate and upload)."""
+import argparse
 import ctypes as C
 import os
 import sys
@@ -10,6 +16,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tstwo_amd import _lib as L  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--cols", type=int, default=256)
+ap.add_argument("--log-size", type=int, default=22)
+ap.add_argument("--cfft-only", action="store_true")
+args = ap.parse_args()
+
 L.init(0)
 vp = lambda p: C.c_void_p(p)
 ncal = 1 << 26
@@ -17,23 +29,31 @@ a, b, o = L.DeviceBuffer(4 * ncal + 16), L.DeviceBuffer(4 * ncal + 16), L.Device
 a.zero(); b.zero(); o.zero()
 L.call("tstwo_m31_add", vp(a.ptr), vp(b.ptr), vp(o.ptr), ncal)                    # k_m31_binop_vec4: 16 B per lane
 L.call("tstwo_m31_add", vp(a.ptr + 4), vp(b.ptr + 4), vp(o.ptr + 4), ncal)        # k_m31_binop_scalar: 4 B per lane
-n, cols = 22, 32
+n, cols = args.log_size, args.cols
 N = 1 << n
 rng = np.random.default_rng(0)
-bufs = []
-for c in range(cols):
-    x = L.DeviceBuffer(4 * N)
-    x.upload(rng.integers(0, L.P, size=N, dtype=np.uint32))
-    bufs.append(x)
+bufs = [L.DeviceBuffer(4 * N) for _ in range(cols)]
+bufs[0].upload(rng.integers(0, L.P, size=N, dtype=np.uint32))
+for x in bufs[1:]:
+    L.call("tstwo_copy", vp(x.ptr), vp(bufs[0].ptr), 4 * N)
 ptrs = L.ptr_array([x.ptr for x in bufs])
 half = 1 << (31 - (n + 1))
 tw = L.DeviceBuffer(2 * N)
 L.call("tstwo_twiddles_build", half, n - 1, vp(tw.ptr), vp(0))
+L.sync()
+if args.cfft_only:
+    for _ in range(2):
+        L.call("tstwo_cfft_evaluate", ptrs, cols, n, half, vp(tw.ptr), n - 1)
+    L.sync()
+    print("done")
+    sys.exit(0)
+tree = 32 if cols % 32 == 0 else cols
 layers = L.DeviceBuffer(32 * ((2 << n) - 1))
 for _ in range(2):
     L.call("tstwo_cfft_evaluate", ptrs, cols, n, half, vp(tw.ptr), n - 1)
-    L.call("tstwo_merkle_commit", ptrs, L.u32x([n] * cols), cols, vp(layers.ptr), None)
-# PolyOps.eval_at_point: one column log 24 (64 MiB read once) + 32 columns log 20 at one point
+    for t in range(0, cols, tree):
+        L.call("tstwo_merkle_commit", L.ptr_array([x.ptr for x in bufs[t:t + tree]]), L.u32x([n] * tree), tree, vp(layers.ptr), None)
+# PolyOps.eval_at_point: one column log 24 (64 MiB read once)
 from tstwo_amd.circle import SECURE_FIELD_CIRCLE_GEN as G  # noqa: E402
 px, py, o4 = L.u32x(G.x.tup()), L.u32x(G.y.tup()), L.u32x([0] * 4)
 big = L.DeviceBuffer(4 << 24)

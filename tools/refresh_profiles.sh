@@ -3,7 +3,7 @@
 # Output goes to gpurun_out/$TAG/ (scratch); tools/collect_profiles.sh copies the summaries into profiles/.
 # Every profiled command sits behind `timeout -k`, and a progress line is printed after each stage.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -11,21 +11,22 @@ export TMPDIR=/tmp
 T="timeout -k 10"
 cd /tmp
 # 1. PMC passes (separate runs, --pmc only): HBM traffic with the guide's gfx950 corrections, then SQ counters
-$T 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/pmc_target.py > $O/pmc_fetch.log 2>&1
-$T 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/pmc_target.py > $O/pmc_write.log 2>&1
+$T 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/tools/pmc_target.py > $O/pmc_fetch.log 2>&1
+$T 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/tools/pmc_target.py > $O/pmc_write.log 2>&1
 echo "pmc traffic done"
-$T 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES --output-format csv -d $O/pmc_sq1 -o s1 -- python3 $R/tools/pmc_target.py > $O/pmc_sq1.log 2>&1
-$T 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq2 -o s2 -- python3 $R/tools/pmc_target.py > $O/pmc_sq2.log 2>&1
+$T 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES --output-format csv -d $O/pmc_sq1 -o s1 -- python3 $R/tools/pmc_target.py > $O/pmc_sq1.log 2>&1
+$T 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq2 -o s2 -- python3 $R/tools/pmc_target.py > $O/pmc_sq2.log 2>&1
 echo "pmc sq done"
 cd $R
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write > $O/cfft_pmc.json
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 22 256 > $O/cfft_pmc.json
 python3 tools/sq_summary.py $O/pmc_sq1 $O/pmc_sq2 > $O/sq_counters.json
 # 2. the bench line (configs 1-4 inside), with the traffic of THIS build
-$T 500 python3 bench.py --steps 20 --warmup 5 --pmc-json $O/cfft_pmc.json > $O/bench.json 2> $O/bench.err
+# (bench.py collects roofline.traffic itself in child rocprofv3 --pmc passes; cfft_pmc.json above is the per-kernel record)
+$T 800 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 echo "bench done"; tail -c 300 $O/bench.json
 # 3. kernel trace + stats of the same command (without the CPU leg and the config sweep) and of the config sweep
 cd /tmp
-$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-configs > $O/stats.log 2>&1
+$T 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --no-configs --no-pmc > $O/stats.log 2>&1
 echo "stats done"
 $T 300 rocprofv3 --kernel-trace --output-format csv -d $O/stats_configs -o configs -- python3 $R/tools/bench_configs.py --no-cpu > $O/stats_configs.log 2>&1
 echo "stats configs done"
@@ -39,3 +40,4 @@ $T 300 python3 tools/bench_callers.py > $O/callers.jsonl 2> $O/callers.err
 echo "callers done"
 rm -rf $O/stats $O/stats_configs $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces are large; summaries are what is kept
 ls -la $O
+sha256sum $R/tstwo_amd/libtstwo_hip.so | cut -c1-16 > $O/lib_sha16.txt
