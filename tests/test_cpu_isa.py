@@ -4,7 +4,8 @@ disassembled with llvm-objdump; nothing is executed).  These are the properties 
     every light run is made of VOP2 add/sub/xor/shift only and no heavy VALU instruction sits inside one;
   * column data is accessed with global_* instructions (a flat_* access also counts on lgkmcnt and would make the LDS-only
     barriers wait for in-flight prefetches);
-  * nothing spills inside the phased kernels' hot loops beyond the few prologue dwords already recorded in DESIGN."""
+  * the four headline CFFT pass kernels (2^13 bottom pass, 9-layer strided pass, both directions) and the Blake2s leaf / inner
+    kernels use no scratch memory at all (no scratch_load / scratch_store in their ISA)."""
 import os
 import re
 import shutil
@@ -72,6 +73,7 @@ def test_hot_kernels_are_phased_and_use_global_memory_instructions(tu, pattern, 
     assert len(names) == 1, names
     ins = kernels[names[0]]
     assert not [i for i in ins if i.startswith(("flat_load", "flat_store"))], "column data must not be accessed with flat_* instructions"
+    assert not [i for i in ins if i.startswith("scratch_")], "the headline kernels must not spill (ScratchSize 0)"
     phases = _phases(ins)
     assert len(phases) >= min_phases, len(phases)
     light_runs = [p for p in phases if p[0] == 0 and len(p[1]) >= 4]
@@ -90,3 +92,4 @@ def test_hot_kernels_are_phased_and_use_global_memory_instructions(tu, pattern, 
             cur = cur + 1 if _is_light(i) else 0
             longest = max(longest, cur)
         assert longest <= 12, (names[0], longest)
+

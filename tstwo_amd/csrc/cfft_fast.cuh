@@ -71,13 +71,13 @@ __device__ __forceinline__ void groups_layers(u32 (&v)[NG][1 << G], const u32 *t
 
 // In-place LDS stage: every lane handles 16 >> G groups of 2^G words.
 template <int G, int Q, int LOGT, int THREADS, bool INV>
-__device__ __forceinline__ void lds_stage(u32 *lds, const u32 *twl) {
+__device__ __forceinline__ void lds_stage(u32 *lds, const u32 *twl, u32 tid) {
     constexpr int NG = 16 >> G;
     u32 v[NG][1 << G], high[NG];
     u32 *p[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-        u32 gid = threadIdx.x + (u32)g * THREADS;
+        u32 gid = tid + (u32)g * THREADS;
         if (Q == 4) gid = (gid & ~0x30u) | ((gid & 0x10u) << 1) | ((gid & 0x20u) >> 1);   // bank-conflict-free lane -> group map
         const u32 low = gid & ((1u << Q) - 1u);
         high[g] = gid >> Q;
@@ -186,8 +186,11 @@ template <> struct SrcTable<0> { using type = NoSrc; };
 // Bottom pass: layers 0..LOGT-1 (circle layer included) of a contiguous 2^LOGT-word tile, LOGT in 11..13
 // (2^(LOGT-4) lanes).  LOGT = 13 is the default; smaller tiles give more workgroups when there are few columns.
 // OOP: tiles are read from `src` (left untouched) and written to `cols` — the first pass of an out-of-place interpolation.
+#ifndef TSTWO_B_WAVES
+#define TSTWO_B_WAVES 6
+#endif
 template <bool INV, int LOGT, bool OOP = false>
-__global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typename SrcTable<OOP ? 1 : 0>::type src, u32 n_cols, u32 total_items,
+__global__ void __launch_bounds__(1 << (LOGT - 4), TSTWO_B_WAVES) k_cfft_b(ColPtrs cols, typename SrcTable<OOP ? 1 : 0>::type src, u32 n_cols, u32 total_items,
                                                  u32 n, const u32 *__restrict__ tw_end, u32 scale) {
     constexpr int THREADS = 1 << (LOGT - 4);
     constexpr int GM = LOGT - 10;              // layers of the middle LDS stage (bits [8, LOGT-2))
@@ -220,22 +223,27 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
     // waited for each one in turn (five round trips, ~5 us per launch of a few-column transform).
     uint4 pf[4];
     u32 t1[4], t2[2], t3, ta, tb0, tb1;
-    // word offset of the lane's 16-byte piece in its wave's 1024 consecutive words (x 4 pieces 256 words apart): the
-    // coalesced form of the lane's 16 consecutive words 16t .. 16t+15 (forward pass: final stores)
-    const u32 e0w = ((t >> 6) << 10) + 4 * (t & 63);
+    // (forward pass, final stores: e0 = ((t >> 6) << 10) + 4 (t & 63) is the word offset of the lane's 16-byte piece in its
+    // wave's 1024 consecutive words, x 4 pieces 256 words apart — the coalesced form of the lane's 16 consecutive words)
     {
+        u32 tp = t;                          // opaque per tile run: keeps the prologue's lane addresses out of kernel-lifetime registers
+        asm volatile("" : "+v"(tp));
         const u32 *__restrict__ d = src_of(col0);
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            pf[j] = INV ? gload4(d, 16 * t + 4 * j) : gload4(d + 4 * t + j * QT);
-        uint4 q1 = gload4(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)) + 4 * t);
-        uint2 q2 = gload2(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)) + 2 * t);
-        u32 q3 = tw_end[-(ptrdiff_t)((size_t)1 << (n - 3)) + (ptrdiff_t)(((size_t)hi << (LOGT - 4)) + t)];
+            pf[j] = INV ? gload4(d, 16 * tp + 4 * j) : gload4(d + 4 * tp + j * QT);
+        // (twiddle loads as wave-uniform base + 32-bit lane offset: a 64-bit address pair per load, all of them live at once
+        // because the loads are issued back to back, is what used to spill in this prologue)
+        uint4 q1 = gload4(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)), 4 * tp);
+        uint2 q2 = gload2(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)), 2 * tp);
+        u32 q3 = gload1(tw_end - ((size_t)1 << (n - 3)) + ((size_t)hi << (LOGT - 4)), tp);
         // heap: level lv in 2..LOGT-5 holds layer bit b = LOGT-1 - lv (lanes 0..3 have no entry: they load lane 4's and drop it)
-        const u32 th = max(t, 4u);
+        const u32 th = max(tp, 4u);
         const u32 lv = 31u - (u32)__clz(th);
         const u32 hb = (u32)(LOGT - 1) - lv;
-        u32 hv = tw_end[-(ptrdiff_t)((size_t)1 << (n - hb)) + (ptrdiff_t)(((size_t)hi << lv) + (th - (1u << lv)))];
+        // its word lies 2^(n-hb) - (hi << lv) - (th - 2^lv) words below tw_end, hb >= 4: within 2^(n-4) words of it
+        const u32 hoff = (1u << (n - 4)) - (1u << (n - hb)) + (hi << lv) + (th - (1u << lv));
+        u32 hv = gload1(tw_end - ((size_t)1 << (n - 4)), hoff);
         u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 1))) + (ptrdiff_t)hi];           // layer LOGT-1 / LOGT-2 (wave-uniform)
         u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
         u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
@@ -243,7 +251,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
         t1[0] = q1.x + q1.x; t1[1] = q1.y + q1.y; t1[2] = q1.z + q1.z; t1[3] = q1.w + q1.w;
         t2[0] = q2.x + q2.x; t2[1] = q2.y + q2.y;
         t3 = q3 + q3;
-        if (t >= 4) twl[t] = hv + hv;
+        if (tp >= 4) twl[tp] = hv + hv;
         ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
     }
     if (INV) lds_barrier();      // the inverse reads the heap in its first LDS stage, which no workgroup barrier precedes
@@ -251,36 +259,43 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
     for (u32 col = col0; col < col1; col++) {
         u32 *__restrict__ data = colp_u(cols, col) + base;
         const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
+        // Opaque per iteration (inverse and the 2^11 tile): the LDS addresses of the stages (about twenty, all functions of the
+        // lane id) are then recomputed per column instead of living in registers for the whole kernel — hoisted, they spilled
+        // (one scratch reload inside this loop).  The forward 2^12 / 2^13 kernels fit without it, and there the ~20 extra address
+        // instructions per column cost more than they free: 3.92 against 3.85 ms for 256 x 2^22 (gpurun_out/r03b/ab1.log).
+        u32 tt = t;
+        if (INV || LOGT == 11) asm volatile("" : "+v"(tt));
         if (!INV) {
             top_layers<false, true>(pf, ta, tb0, tb1);                    // layers LOGT-1, LOGT-2
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
+                u32 *p = lds + pad(4 * tt) + j * (QT + QT / 32);
                 p[0] = pf[j].x; p[1] = pf[j].y; p[2] = pf[j].z; p[3] = pf[j].w;
             }
             lds_barrier();
 #pragma unroll
             for (int j = 0; j < 4; j++) pf[j] = gload4(next + 4 * t + j * QT);   // (pointer form: the base + 32-bit offset form costs this kernel registers it does not have: +17 us)
-            lds_stage<GM, 8, LOGT, THREADS, false>(lds, twl);              // layers LOGT-3..8
+            lds_stage<GM, 8, LOGT, THREADS, false>(lds, twl, tt);              // layers LOGT-3..8
             lds_barrier();
-            lds_stage<4, 4, LOGT, THREADS, false>(lds, twl);               // layers 7..4
+            lds_stage<4, 4, LOGT, THREADS, false>(lds, twl, tt);               // layers 7..4
             lds_wave_fence();    // the 256-word blocks a wave wrote in that stage are the ones it reads now: no workgroup barrier
             u32 v[16];
 #pragma unroll
-            for (int m = 0; m < 16; m++) v[m] = lds[pad(16 * t) + m];
+            for (int m = 0; m < 16; m++) v[m] = lds[pad(16 * tt) + m];
             low_layers<false>(v, t1, t2, t3);                              // layers 3, 2, 1 and the circle layer
             // The lane now holds 16 consecutive words (64 bytes): stored as they are, every store instruction would touch 64
             // separate 64-byte segments a quarter each.  One more trip through the wave's own 1024 words of LDS turns them
             // into four 1 KiB-contiguous 16-byte-per-lane stores (wave-local: no workgroup barrier).
             lds_wave_fence();
 #pragma unroll
-            for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
+            for (int m = 0; m < 16; m++) lds[pad(16 * tt) + m] = v[m];
             lds_wave_fence();
-            const u32 e0 = e0w;
+            const u32 e0 = ((tt >> 6) << 10) + 4 * (tt & 63);
             uint4 o[4];
+            const u32 *pe0 = lds + pad(e0);       // pad(e0 + 256 j) = pad(e0) + 264 j: e0's bits 8, 9 are clear
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const u32 *p = lds + pad(e0 + 256 * j);
+                const u32 *p = pe0 + 264 * j;
                 o[j] = make_uint4(p[0], p[1], p[2], p[3]);
             }
             lds_barrier();       // last LDS access of this column: the next column's tile may overwrite it
@@ -294,18 +309,18 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), 6) k_cfft_b(ColPtrs cols, typ
             for (int j = 0; j < 4; j++) { v[4 * j] = pf[j].x; v[4 * j + 1] = pf[j].y; v[4 * j + 2] = pf[j].z; v[4 * j + 3] = pf[j].w; }
             low_layers<true>(v, t1, t2, t3);
 #pragma unroll
-            for (int m = 0; m < 16; m++) lds[pad(16 * t) + m] = v[m];
+            for (int m = 0; m < 16; m++) lds[pad(16 * tt) + m] = v[m];
             lds_wave_fence();    // the next stage reads the blocks this wave has just written
 #pragma unroll
             for (int j = 0; j < 4; j++) pf[j] = gload4(next, 16 * t + 4 * j);
-            lds_stage<4, 4, LOGT, THREADS, true>(lds, twl);
+            lds_stage<4, 4, LOGT, THREADS, true>(lds, twl, tt);
             lds_barrier();
-            lds_stage<GM, 8, LOGT, THREADS, true>(lds, twl);
+            lds_stage<GM, 8, LOGT, THREADS, true>(lds, twl, tt);
             lds_barrier();
             uint4 x[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
+                const u32 *p = lds + pad(4 * tt) + j * (QT + QT / 32);
                 x[j] = make_uint4(p[0], p[1], p[2], p[3]);
             }
             lds_barrier();       // last LDS access of this column (see the forward branch)
@@ -443,7 +458,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
                 lds_barrier();
                 load_tile(next);
                 if constexpr (G1 > 0) {
-                    lds_stage<G1, C + 4, LOGT, THREADS, false>(lds, twl);
+                    lds_stage<G1, C + 4, LOGT, THREADS, false>(lds, twl, t);
                     lds_barrier();
                 }
                 // final stage: butterflies, then straight to HBM (rows of 2^C words: >= 128 B per half-wave)
@@ -513,7 +528,7 @@ __global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typena
 #pragma unroll
                 for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(next, goff(e_final(tt, g, m)));
             if constexpr (G1 > 0) {
-                lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl);
+                lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl, t);
                 lds_barrier();
             }
             uint4 x[4];

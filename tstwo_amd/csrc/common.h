@@ -101,6 +101,10 @@ __device__ __forceinline__ uint4 gload4(const u32 *base, u32 word_off) {
     const u32x4_t v = *(const TSTWO_GLOBAL u32x4_t *)((const TSTWO_GLOBAL char *)base + (word_off << 2));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint2 gload2(const u32 *base, u32 word_off) {
+    const u32x2_t v = *(const TSTWO_GLOBAL u32x2_t *)((const TSTWO_GLOBAL char *)base + (word_off << 2));
+    return make_uint2(v.x, v.y);
+}
 __device__ __forceinline__ u32 gload1(const u32 *base, u32 word_off) { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)base + (word_off << 2)); }
 __device__ __forceinline__ void gstore4(u32 *base, u32 word_off, uint4 x) {
     u32x4_t v;

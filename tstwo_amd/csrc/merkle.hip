@@ -200,6 +200,11 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
 #pragma unroll
         for (int k = 0; k < 16; k++) cur[k] = word(k, oc);
     }
+    // The digest of node j is stored one compression LATER (behind the loads of node j + 1's first block): the compiler waits
+    // vmcnt(0) at the loop header, so a store issued at the end of an iteration has its whole write latency exposed there
+    // (gfx9 stores count on vmcnt); issued here it has a full compression to complete.  Costs 8 VGPRs.
+    u32 hp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t pnode = n_nodes;                                       // node whose digest is waiting in hp (none yet)
     for (u32 j = 0; j < rows; j++) {
         const size_t node = node0 + (size_t)j * stride;
         const size_t nn = min(node + stride, last_node);          // next node of this lane (clamped: loads are never branched around)
@@ -216,6 +221,16 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
 #else
             for (int k = 0; k < 16; k++) nxt[k] = word(16 * bn + k, src);
 #endif
+            if (b == 0 && pnode < n_nodes) {
+#ifdef TSTWO_EXP_LEAF_COALESCED_STORE      // experiment: upper bound of coalesced digest stores (WRONG layout)
+                const size_t wb = 2 * (pnode - (threadIdx.x & 63));
+                out[wb + (threadIdx.x & 63)] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                out[wb + 64 + (threadIdx.x & 63)] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+#else
+                out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+#endif
+            }
 #ifdef TSTWO_EXP_LEAF_NOHASH      // experiment: the kernel's memory side alone (WRONG results)
 #pragma unroll
             for (int k = 0; k < 16; k++) h[k & 7] ^= cur[k];
@@ -225,18 +240,13 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
 #pragma unroll
             for (int k = 0; k < 16; k++) cur[k] = nxt[k];
         }
-#ifdef TSTWO_EXP_LEAF_COALESCED_STORE      // experiment: upper bound of coalesced digest stores (WRONG layout)
-        if (node < n_nodes) {
-            const size_t wb = 2 * (node - (threadIdx.x & 63));
-            out[wb + (threadIdx.x & 63)] = make_uint4(h[0], h[1], h[2], h[3]);
-            out[wb + 64 + (threadIdx.x & 63)] = make_uint4(h[4], h[5], h[6], h[7]);
-        }
-#else
-        if (node < n_nodes) {
-            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
-            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
-        }
-#endif
+#pragma unroll
+        for (int k = 0; k < 8; k++) hp[k] = h[k];
+        pnode = node;
+    }
+    if (pnode < n_nodes) {
+        out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
     }
 }
 
@@ -251,19 +261,36 @@ __global__ void __launch_bounds__(256) k_merkle_leaf4(const u32 *__restrict__ c0
     auto word = [&](const u32 *col, u32 byte_off) -> u32 { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)col + byte_off); };
     const u32 o0 = (u32)min(node0, last_node) * 4u;       // scalar base + one 32-bit offset (log_size <= 30: host)
     u32 a = word(c0, o0), b = word(c1, o0), c = word(c2, o0), d = word(c3, o0);
+    u32 hp[8] = {0, 0, 0, 0, 0, 0, 0, 0};                        // deferred store: see k_merkle_leaf_static
+    size_t pnode = n_nodes;
     for (u32 j = 0; j < rows; j++) {
         const size_t node = node0 + (size_t)j * stride;
         const size_t nn = min(node + stride, last_node);
         const u32 on = (u32)nn * 4u;
+#ifdef TSTWO_EXP_L4_NOLOAD       // experiment: ALU + stores only (WRONG results)
+        const u32 na = a + on, nb = b ^ on, ncc = c + 1u, nd = d + on;
+#else
         const u32 na = word(c0, on), nb = word(c1, on), ncc = word(c2, on), nd = word(c3, on);      // next node's words in flight during the compression
+#endif
+#ifdef TSTWO_EXP_L4_NOSTORE      // experiment: (practically) no stores (WRONG results)
+        if (pnode < n_nodes && hp[0] == 0x12345678u && hp[1] == 0x9abcdef0u) {
+#else
+        if (pnode < n_nodes) {
+#endif
+            out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+        }
         u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
         const u32 m[16] = {a, b, c, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         b2s_compress(h, m, 16u, true);
-        if (node < n_nodes) {
-            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
-            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
-        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) hp[k] = h[k];
+        pnode = node;
         a = na; b = nb; c = ncc; d = nd;
+    }
+    if (pnode < n_nodes) {
+        out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
     }
 }
 
@@ -278,19 +305,28 @@ __global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ 
         const uint4 *p = prev + 4 * min(node0, last_node);
         c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3];
     }
+    u32 hp[8] = {0, 0, 0, 0, 0, 0, 0, 0};                        // deferred store: see k_merkle_leaf_static
+    size_t pnode = n_nodes;
     for (u32 j = 0; j < rows; j++) {
         const size_t node = node0 + (size_t)j * stride;
         const uint4 *pn = prev + 4 * min(node + stride, last_node);
         cn[0] = pn[0]; cn[1] = pn[1]; cn[2] = pn[2]; cn[3] = pn[3];
+        if (pnode < n_nodes) {
+            out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
+        }
         u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
         const u32 m[16] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w,
                            c[2].x, c[2].y, c[2].z, c[2].w, c[3].x, c[3].y, c[3].z, c[3].w};
         b2s_compress(h, m, 64u, true);
-        if (node < n_nodes) {
-            out[2 * node] = make_uint4(h[0], h[1], h[2], h[3]);
-            out[2 * node + 1] = make_uint4(h[4], h[5], h[6], h[7]);
-        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) hp[k] = h[k];
+        pnode = node;
         c[0] = cn[0]; c[1] = cn[1]; c[2] = cn[2]; c[3] = cn[3];
+    }
+    if (pnode < n_nodes) {
+        out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
     }
 }
 
@@ -341,7 +377,21 @@ template <int LEVELS>
 __global__ void __launch_bounds__(256) k_merkle_subtree(uint4 *__restrict__ layers, u32 log_child) {
     const size_t top = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         // node index in layer log_child - LEVELS
     if (top >= ((size_t)1 << (log_child - LEVELS))) return;
-    (void)subtree_node<LEVELS>(layers, log_child, top);
+    if constexpr (LEVELS == 2) {
+        // straight-line form of the two-level subtree: all four children are requested before anything is hashed (the rolled
+        // recursion loads a pair, waits, hashes, stores, and waits vmcnt(0) for that store before it loads the next pair), and
+        // every store is followed by a compression or by the end of the wave, so no write latency is ever waited for
+        const uint4 *c = layers + 2 * ((((size_t)1 << log_child) - 1) + 4 * top);
+        const Digest c0 = load_digest(c), c1 = load_digest(c + 2), c2 = load_digest(c + 4), c3 = load_digest(c + 6);
+        uint4 *mid = layers + 2 * ((((size_t)1 << (log_child - 1)) - 1) + 2 * top);
+        const Digest l = hash_pair(c0, c1);
+        store_digest(mid, l);
+        const Digest r = hash_pair(c2, c3);
+        store_digest(mid + 2, r);
+        store_digest(layers + 2 * ((((size_t)1 << (log_child - 2)) - 1) + top), hash_pair(l, r));
+    } else {
+        (void)subtree_node<LEVELS>(layers, log_child, top);
+    }
 }
 
 // Several column-free levels per launch: a workgroup of WG lanes owns 2*WG consecutive nodes of layer `log_child`
