@@ -147,6 +147,9 @@ def run_configs(reps=10, no_cpu=False, emit_line=None):
                                                         [(point.x.tup(), point.y.tup(), [(c, vals[c].tup()) for c in range(4)])]),
                        1 << s, "rows", "2^18 rows (same per-row work)")
     emit(3, "accumulate_quotients C=4 log 22 (C-ABI call: constant upload + kernel + error-flag readback)", ms, 32.0 * N, N, "rows", cpu)
+    ms = timed(lambda: L.call("tstwo_quotients_accumulate_async", *qargs, qout.ptrs()), reps=args.reps)
+    L.call("tstwo_check_zero_flag")
+    emit(3, "accumulate_quotients_async C=4 log 22 (constant upload + kernel; zero check deferred to one tstwo_check_zero_flag per phase)", ms, 32.0 * N, N, "rows")
     sec_h = [splitmix_column(8 + c, N) for c in range(4)]
     for c in sec_h:
         c[c == 0] = 1
@@ -155,6 +158,9 @@ def run_configs(reps=10, no_cpu=False, emit_line=None):
     ms = timed(lambda: L.call("tstwo_qm31_batch_inverse", sec.ptrs(), out4.ptrs(), N), reps=5)
     cpu = cpu_time(lambda: orc.qm31_batch_inverse([c[: 1 << 18] for c in sec_h]), 1 << 18, "elems", "2^18 elements") if not args.no_cpu else None
     emit(3, "qm31_batch_inverse log 22", ms, 32.0 * N, N, "elems", cpu)
+    ms = timed(lambda: L.call("tstwo_qm31_batch_inverse_async", sec.ptrs(), out4.ptrs(), N), reps=args.reps)
+    L.call("tstwo_check_zero_flag")
+    emit(3, "qm31_batch_inverse_async log 22 (kernel only; zero check deferred)", ms, 32.0 * N, N, "elems")
 
     # ---------------------------------------------------------------- config 4: fold_circle_into_line + Merkle (C=4), log 24
     n = 24

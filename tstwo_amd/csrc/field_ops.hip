@@ -5,6 +5,7 @@
 // bytes per element: add/sub/mul 12 B, neg 8 B, m31 batch inverse 8 B,
 // qm31 batch inverse 32 B, bit reverse 8 B.
 #include "common.h"
+#include "field8.cuh"
 
 using namespace tstwo;
 
@@ -183,6 +184,95 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_v4(CSoa4 in, Soa4 ou
         gstore4(out.p[1] + i, make_uint4(r[4 * g].b, r[4 * g + 1].b, r[4 * g + 2].b, r[4 * g + 3].b));
         gstore4(out.p[2] + i, make_uint4(r[4 * g].c, r[4 * g + 1].c, r[4 * g + 2].c, r[4 * g + 3].c));
         gstore4(out.p[3] + i, make_uint4(r[4 * g].d, r[4 * g + 1].d, r[4 * g + 2].d, r[4 * g + 3].d));
+    }
+}
+
+// QM31 batch inverse through the norms.  The inverse of x = c0 + c1 u (c0 = a + bi, c1 = c + di; fields/qm31.ts:282-305) is
+//   x^-1 = (c0 - c1 u) / D,  D = c0^2 - (2 + i) c1^2 in CM31,   D^-1 = conj(D) / n,  n = D.re^2 + D.im^2 in M31,
+// so the only inversion is of the M31 norm n — and batchInverse (fields/fields.ts:66-207) returns the unique elementwise
+// inverse whatever the schedule.  A lane owns 8 elements (two runs of 4 consecutive ones: 16-byte accesses); their 8 norms
+// share one Fermat chain (f8::inverse8).  Per element: 9 + 2 + 8 multiply-adds, 10 lazy reductions and 5 multiplications
+// (~210 VALU instructions) against 3 QM31 products (~320) in Montgomery's trick over QM31 values, and every step is the same
+// operation on 8 independent elements, issued in priority phases (field8.cuh).
+//   D.re = a a + b (P-b) + c 2(d-c)  +  d 2d          D.im = a 2b + c 2(P-d)  +  c 2(P-d) + c (P-c) + d d
+//   out  = (a ir + b (P-ii),  a ii + b ir,  c (P-ir) + d ii,  c (P-ii) + d (P-ir)),   (ir, ii) = (D.re, P - D.im) / n
+// (sums of at most 4 units of (P-1)P per 64-bit accumulator, doubled operands count twice: m31.cuh, qm31_mul).
+__global__ void __launch_bounds__(256) k_qm31_batch_inverse_norm(CSoa4 in, Soa4 out, size_t T, u32 *flag) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const u32 P = vgpr_P();
+    u32 a[8], b[8], c[8], d[8];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const size_t i = 4 * (t + (size_t)g * T);
+        const uint4 va = gload4(in.p[0] + i), vb = gload4(in.p[1] + i), vc = gload4(in.p[2] + i), vd = gload4(in.p[3] + i);
+        a[4 * g] = va.x; a[4 * g + 1] = va.y; a[4 * g + 2] = va.z; a[4 * g + 3] = va.w;
+        b[4 * g] = vb.x; b[4 * g + 1] = vb.y; b[4 * g + 2] = vb.z; b[4 * g + 3] = vb.w;
+        c[4 * g] = vc.x; c[4 * g + 1] = vc.y; c[4 * g + 2] = vc.z; c[4 * g + 3] = vc.w;
+        d[4 * g] = vd.x; d[4 * g + 1] = vd.y; d[4 * g + 2] = vd.z; d[4 * g + 3] = vd.w;
+    }
+    bool zero = false;
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if ((a[e] | b[e] | c[e] | d[e]) == 0) { zero = true; a[e] = 1u; }
+    if (zero) atomicOr(flag, 1u);
+    // operands: dmc2 = 2 (d - c mod P), d2 = 2d, b2 = 2b, nb = P - b, nc = P - c, nd2 = 2 (P - d)
+    u32 dmc[8], dmc2[8], d2[8], b2[8], nb[8], nc[8], nd2[8];
+    f8::sub(dmc, d, c);
+    f8::done();
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        dmc2[e] = dmc[e] + dmc[e]; d2[e] = d[e] + d[e]; b2[e] = b[e] + b[e];
+        nb[e] = P - b[e]; nc[e] = P - c[e]; nd2[e] = (P - d[e]) + (P - d[e]);
+    }
+    u64 re0[8], re1[8], im0[8], im1[8];
+    f8::pin(a); f8::pin(b); f8::pin(c); f8::pin(d);      // every operand of the multiply-add run passes through its boundary
+    f8::pin(dmc2); f8::pin(d2); f8::pin(b2); f8::pin(nb); f8::pin(nc);
+    phase<kPrioHeavy>(nd2);
+    f8::mul64(re0, a, a); f8::mad(re0, b, nb); f8::mad(re0, c, dmc2);
+    f8::mul64(re1, d, d2);
+    f8::mul64(im0, a, b2); f8::mad(im0, c, nd2);
+    f8::mul64(im1, c, nd2); f8::mad(im1, c, nc); f8::mad(im1, d, d);
+    f8::pin(re1); f8::pin(im0); f8::pin(im1);
+    u32 r0[8], r1[8], i0[8], i1[8], dr[8], di[8];
+    f8::reduce(r0, re0); f8::reduce<false>(r1, re1); f8::reduce(i0, im0); f8::reduce(i1, im1);
+    f8::add(dr, r0, r1);
+    f8::add(di, i0, i1);
+    // norms and their inverses
+    u64 nn[8];
+    u32 n[8], ninv[8];
+    f8::pin(dr);
+    phase<kPrioHeavy>(di);
+    f8::mul64(nn, dr, dr); f8::mad(nn, di, di);
+    f8::reduce<false>(n, nn);
+    f8::inverse8(ninv, n);
+    // (ir, ii) = (dr, P - di) / n, then the four output coordinates
+    u32 ir[8], ii[8], ndi[8], nir[8], nii[8];
+    f8::neg_operand(ndi, di);
+    f8::mul(ir, dr, ninv);
+    f8::mul(ii, ndi, ninv);
+    f8::done();
+    f8::neg_operand(nir, ir);
+    f8::neg_operand(nii, ii);
+    u64 oa[8], ob[8], oc[8], od[8];
+    f8::pin(a); f8::pin(b); f8::pin(c); f8::pin(d); f8::pin(ir); f8::pin(ii); f8::pin(nir);
+    phase<kPrioHeavy>(nii);
+    f8::mul64(oa, a, ir); f8::mad(oa, b, nii);
+    f8::mul64(ob, a, ii); f8::mad(ob, b, ir);
+    f8::mul64(oc, c, nir); f8::mad(oc, d, ii);
+    f8::mul64(od, c, nii); f8::mad(od, d, nir);
+    f8::pin(ob); f8::pin(oc); f8::pin(od);
+    u32 xa[8], xb[8], xc[8], xd[8];
+    f8::reduce<false>(xa, oa); f8::reduce<false>(xb, ob); f8::reduce<false>(xc, oc); f8::reduce<false>(xd, od);
+    f8::pin(xa); f8::pin(xb); f8::pin(xc);
+    phase<kPrioLight>(xd);
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const size_t i = 4 * (t + (size_t)g * T);
+        gstore4(out.p[0] + i, make_uint4(xa[4 * g], xa[4 * g + 1], xa[4 * g + 2], xa[4 * g + 3]));
+        gstore4(out.p[1] + i, make_uint4(xb[4 * g], xb[4 * g + 1], xb[4 * g + 2], xb[4 * g + 3]));
+        gstore4(out.p[2] + i, make_uint4(xc[4 * g], xc[4 * g + 1], xc[4 * g + 2], xc[4 * g + 3]));
+        gstore4(out.p[3] + i, make_uint4(xd[4 * g], xd[4 * g + 1], xd[4 * g + 2], xd[4 * g + 3]));
     }
 }
 
@@ -370,7 +460,11 @@ int tstwo_qm31_batch_inverse_async(const u32 *const in[4], u32 *const out[4], si
     bool aligned = true;
     for (int k = 0; k < 4; k++) aligned = aligned && ((((uintptr_t)in[k]) | ((uintptr_t)out[k])) & 15) == 0;
     static const int kq = [] { const char *e = getenv("TSTWO_QINV_K"); return e ? atoi(e) : 0; }();      // experiments: 4-byte form, K per lane
-    if (kq == 0 && aligned && n % 8 == 0 && n >= 8) {           // 16-byte accesses, 8 elements per lane
+    static const bool mont = getenv("TSTWO_QINV_MONTGOMERY") != nullptr;      // A/B timing: Montgomery's trick over QM31 values
+    if (kq == 0 && aligned && n % 8 == 0 && n >= 8 && !mont) {  // 16-byte accesses, 8 elements per lane, one M31 inversion per 8
+        size_t T = n / 8;
+        hipLaunchKernelGGL(k_qm31_batch_inverse_norm, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i4, o4, T, ctx().flag);
+    } else if (kq == 0 && aligned && n % 8 == 0 && n >= 8) {
         size_t T = n / 8;
         hipLaunchKernelGGL(k_qm31_batch_inverse_v4<2>, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i4, o4, T, ctx().flag);
     } else if (kq == 0 && aligned && n % 4 == 0 && n >= 4) {

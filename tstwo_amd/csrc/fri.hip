@@ -64,6 +64,10 @@ __global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t
     }
 }
 
+// (A form with a lane owning 4 consecutive output rows — every access 16 bytes per lane instead of 8 / 4 — was built and
+// measured in round 3: fold_circle_into_line log 24 103.9 against 106.7 us, fold_line log 23 37.9 against 35.3 us: the
+// folds already move 5.0 - 5.9 TB/s and the 120 VGPRs of the 4-row form cost as much occupancy as the wider accesses
+// gain.  Removed; gpurun_out/r03b/f1.log.)
 // backend/cpu/fri.ts:97-123: sums of the two halves of each coordinate column (exact in u64).
 __global__ void __launch_bounds__(256) k_half_sums(CSoa4 in, size_t n, unsigned long long *sums /* [4][2] */) {
     __shared__ unsigned long long sh[256 / 64];
@@ -246,6 +250,16 @@ qm31 to_q(const u32 a[4]) { return {a[0], a[1], a[2], a[3]}; }
 qm31 to_q(host::Q a) { return {a.v[0], a.v[1], a.v[2], a.v[3]}; }
 host::Q to_hq(const u32 a[4]) { host::Q q; for (int i = 0; i < 4; i++) q.v[i] = a[i]; return q; }
 
+static void launch_fold_line(const CSoa4 &i4, const Soa4 &o4, size_t n_out, const u32 *inv_x, qm31 alpha, const qm31 *alpha_dev) {
+    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, alpha, alpha_dev);
+}
+static void launch_fold_circle(bool from_tree, const Soa4 &d4, const CSoa4 &s4, size_t n_out, const u32 *twp, qm31 a, qm31 a2, const qm31 *alpha_dev) {
+    if (from_tree)
+        hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, d4, s4, n_out, twp, a, a2, alpha_dev);
+    else
+        hipLaunchKernelGGL(k_fold_circle<false>, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, d4, s4, n_out, twp, a, a2, alpha_dev);
+}
+
 }  // namespace
 
 extern "C" {
@@ -258,7 +272,7 @@ int tstwo_fri_fold_line_tw(const u32 *const in[4], u32 log_n, const u32 *inv_x, 
     size_t n_out = (size_t)1 << (log_n - 1);
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
-    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, to_q(alpha), (const qm31 *)nullptr);
+    launch_fold_line(i4, o4, n_out, inv_x, to_q(alpha), nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -282,11 +296,7 @@ static int fold_circle_common(bool from_tree, u32 *const dst[4], size_t dst_len,
     host::Q a2 = host::qmul(a, a);
     Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
     CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
-    unsigned blocks = capped_blocks(dst_len, 256);
-    if (from_tree)
-        hipLaunchKernelGGL(k_fold_circle<true>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2), (const qm31 *)nullptr);
-    else
-        hipLaunchKernelGGL(k_fold_circle<false>, dim3(blocks), dim3(256), 0, ctx().stream, d4, s4, dst_len, twp, to_q(a), to_q(a2), (const qm31 *)nullptr);
+    launch_fold_circle(from_tree, d4, s4, dst_len, twp, to_q(a), to_q(a2), nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -319,8 +329,7 @@ int tstwo_fri_fold_line_dev(const u32 *const in[4], u32 log_n, const u32 *itw, u
     const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << log_n);
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
-    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, seg, qm31{0, 0, 0, 0},
-                       (const qm31 *)alpha_dev);
+    launch_fold_line(i4, o4, n_out, seg, qm31{0, 0, 0, 0}, (const qm31 *)alpha_dev);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -337,8 +346,7 @@ int tstwo_fri_fold_circle_into_line_dev(u32 *const dst[4], size_t dst_len, const
     const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (log_n - 1));
     Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
     CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
-    hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(dst_len, 256)), dim3(256), 0, ctx().stream, d4, s4, dst_len, seg1,
-                       qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha_dev);
+    launch_fold_circle(true, d4, s4, dst_len, seg1, qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha_dev);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -366,7 +374,7 @@ int tstwo_fri_fold_line_rows(const u32 *const in[4], u32 log_n, size_t row_offse
     const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << log_n) + row_offset;
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
-    hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, i4, o4, n_rows, seg, to_q(alpha), (const qm31 *)nullptr);
+    launch_fold_line(i4, o4, n_rows, seg, to_q(alpha), nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -385,7 +393,7 @@ int tstwo_fri_fold_circle_into_line_rows(u32 *const dst[4], const u32 *const src
     host::Q a2 = host::qmul(a, a);
     Soa4 d4 = {{dst[0], dst[1], dst[2], dst[3]}};
     CSoa4 s4 = {{src[0], src[1], src[2], src[3]}};
-    hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(n_rows, 256)), dim3(256), 0, ctx().stream, d4, s4, n_rows, seg1, to_q(a), to_q(a2), (const qm31 *)nullptr);
+    launch_fold_circle(true, d4, s4, n_rows, seg1, to_q(a), to_q(a2), nullptr);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.h"
+#include "field8.cuh"
 #include "host_field.h"
 
 using namespace tstwo;
@@ -33,15 +34,25 @@ struct Entry {               // 8 words
     u32 pad[3];
 };
 
-__device__ __forceinline__ cpoint domain_point8(cpoint p0, cpoint q4, int s) {
-    // s = row & 7 = (s2 s1 s0): s0 -> conjugate, s1 -> antipode, s2 -> + order-4 point
-    cpoint p = p0;
-    if (s & 4) p = cpoint_add(p, q4);
-    if (s & 2) p = {m31_neg(p.x), m31_neg(p.y)};
-    if (s & 1) p.y = m31_neg(p.y);
-    return p;
+// One lane = 8 consecutive rows = the points p0, conj p0, -p0, conj -p0, p1, conj p1, -p1, conj -p1 with p1 = p0 + Q4
+// (bit-reversed order; Q4 the order-4 point): row s has x = sx[s] * x_{s>>2}, y = sy[s] * y_{s>>2}, sx = + + - -, sy = + - - +.
+// Everything below is the same operation on the 8 rows, issued in priority phases (field8.cuh), and uses the signs:
+//   * numerator  sum_j c_j f_j(row): lazily in 64 bits, 4 column entries per reduction (4 units of (P-1)P);
+//   * A p.y + B and the denominator  C0 + x (P - Pi.y) + y Pi.x  need the products with x0, x1, y0, y1 only (8 + 8
+//     multiplications per batch and lane instead of 32 + 32), rows differ by add / subtract (f8::addsub);
+//   * the 8 CM31 denominators are inverted through their M31 norms n = re^2 + im^2: d^-1 = conj(d) / n, one Fermat chain
+//     per 8 rows (f8::inverse8) — the unique inverses, the values the reference's per-row batchInverse gives;
+//   * term = num * d^-1 (QM31 x CM31): 8 multiply-adds + 4 short reductions per row.
+constexpr unsigned kSignX = 0xCC, kSignY = 0x66;       // bit s set: row s takes the negative x / y of its half
+template <class T>
+__device__ __forceinline__ void bcast(T (&r)[8], T v) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = v;
 }
 
+// SINGLE: one sample batch (the common shape: BASELINE config 3) — a half's rows go straight to memory; otherwise the
+// accumulator of all 8 rows lives in registers across the batches (32 more VGPRs).
+template <bool SINGLE>
 __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
                                                    const BatchConst *__restrict__ batches, u32 n_batches,
                                                    const Entry *__restrict__ entries, Soa4 out,
@@ -52,83 +63,158 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
     // natural index of row 8t: bitrev(t, log_size-3) inside the half coset (log_size-1), step 2^(31-(log_size-1))
     u32 bt = log_size > 3 ? (__brev((u32)t) >> (32 - (log_size - 3))) : 0u;
     u32 idx0 = (half_initial + (bt << (32 - log_size))) & 0x7fffffffu;
-    cpoint p0 = cpoint_from_index_win(idx0, gen_pow2);      // gen_pow2 = Context::gen_win for this kernel
-    cpoint pt[8];
-#pragma unroll
-    for (int s = 0; s < 8; s++) pt[s] = domain_point8(p0, q4, s);
+    const cpoint p0 = cpoint_from_index_win(idx0, gen_pow2);      // gen_pow2 = Context::gen_win for this kernel
+    const cpoint p1 = cpoint_add(p0, q4);
+    u32 xy[8] = {p0.x, p1.x, p0.y, p1.y, p0.x, p1.x, p0.y, p1.y};        // operands of the denominator products (a | b halves)
+    u32 yy[8] = {p0.y, p0.y, p0.y, p0.y, p1.y, p1.y, p1.y, p1.y};        // operands of A * y
 
-    qm31 acc[8];
+    u32 acc[SINGLE ? 1 : 4][8];       // [coordinate][row]
+    if (!SINGLE) {                    // no batch at all: the quotient is zero
 #pragma unroll
-    for (int s = 0; s < 8; s++) acc[s] = {0u, 0u, 0u, 0u};
+        for (int k = 0; k < 4; k++) bcast(acc[SINGLE ? 0 : k], 0u);
+    }
     bool zero = false;
     const size_t row0 = t << 3;
 
     for (u32 b = 0; b < n_batches; b++) {
         const BatchConst bc = batches[b];
-        // numerator: sum_j c_j * f_j(row) accumulated lazily — up to 4 products of < 2^62 (plus the 31-bit running value) fit
-        // 64 bits, so a group of 4 column entries costs 4 v_mad_u64_u32 and ONE reduction per coordinate and row instead of
-        // 4 multiplications with a reduction each and 4 modular additions
-        u32 num[4][8];
+        // ---- denominator, linear in the point: (Pr.x - x) Pi.y - (Pr.y - y) Pi.x = C0 - x Pi.y + y Pi.x per CM31 coordinate
+        const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));       // wave-uniform (scalar unit)
+        u32 ir[8], ii[8];
+        {
+            u32 m8[8] = {M31_P - bc.piy.a, M31_P - bc.piy.a, bc.pix.a, bc.pix.a, M31_P - bc.piy.b, M31_P - bc.piy.b, bc.pix.b, bc.pix.b}, pr[8];
+            f8::mul(pr, xy, m8);       // {x0 npya, x1 npya, y0 pixa, y1 pixa, x0 npyb, x1 npyb, y0 pixb, y1 pixb}
+            u32 da[8], db[8], c8[8], tx[8], ty[8], u[8];
+            bcast(c8, c0.a);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+            for (int s = 0; s < 8; s++) { tx[s] = pr[s >> 2]; ty[s] = pr[2 + (s >> 2)]; }
+            f8::addsub<kSignX>(u, c8, tx);
+            f8::addsub<kSignY>(da, u, ty);
+            bcast(c8, c0.b);
 #pragma unroll
-            for (int s = 0; s < 8; s++) num[k][s] = 0u;
-        for (u32 j = bc.begin; j < bc.end; j += 4) {
-            const u32 cnt = min(4u, bc.end - j);                    // wave-uniform
-            u32 cw[4][4], f[4][8];
+            for (int s = 0; s < 8; s++) { tx[s] = pr[4 + (s >> 2)]; ty[s] = pr[6 + (s >> 2)]; }
+            f8::addsub<kSignX>(u, c8, tx);
+            f8::addsub<kSignY>(db, u, ty);
+            f8::done();
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const Entry en = entries[j + (e < (int)cnt ? e : 0)];          // loads are never branched around; unused products get c = 0
-                const u32 *col = cols[en.col];
-                const uint4 f0 = gload4(col + row0), f1 = gload4(col + row0 + 4);
-                f[e][0] = f0.x; f[e][1] = f0.y; f[e][2] = f0.z; f[e][3] = f0.w; f[e][4] = f1.x; f[e][5] = f1.y; f[e][6] = f1.z; f[e][7] = f1.w;
-                const bool on = e < (int)cnt;
-                cw[e][0] = on ? en.c.a : 0u; cw[e][1] = on ? en.c.b : 0u; cw[e][2] = on ? en.c.c : 0u; cw[e][3] = on ? en.c.d : 0u;
+            for (int s = 0; s < 8; s++)
+                if ((da[s] | db[s]) == 0) { zero = true; da[s] = 1u; }
+            // d^-1 = conj(d) / (re^2 + im^2)
+            u64 nn[8];
+            u32 n[8], ninv[8], ndb[8];
+            f8::pin(da);
+            phase<kPrioHeavy>(db);
+            f8::mul64(nn, da, da); f8::mad(nn, db, db);
+            f8::reduce<false>(n, nn);
+            f8::inverse8(ninv, n);
+            f8::neg_operand(ndb, db);
+            f8::mul(ir, da, ninv);
+            f8::mul(ii, ndb, ninv);
+        }
+        // ---- A y: products A_k y0, A_k y1 (one run of 8); rows differ by the sign of y
+        u32 ay[8];
+        {
+            u32 a8[8] = {bc.A.a, bc.A.b, bc.A.c, bc.A.d, bc.A.a, bc.A.b, bc.A.c, bc.A.d};
+            f8::mul(ay, a8, yy);
+        }
+        // ---- per half (4 rows = one 16-byte load per column entry): numerator, num - (A y + B), term, accumulate.
+        // 8-wide arrays hold [coordinate 2h of the 4 rows | coordinate 2h + 1 of the 4 rows].
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            u32 num[2][8];
+            bool first = true;
+            for (u32 j = bc.begin; j < bc.end; j += 4) {
+                const u32 cnt = min(4u, bc.end - j);                    // wave-uniform
+                u32 cw[4][4], f[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const Entry en = entries[j + (e < (int)cnt ? e : 0)];          // loads are never branched around; unused products get c = 0
+                    const uint4 fv = gload4(cols[en.col] + row0 + 4 * half);
+                    f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
+                    const bool on = e < (int)cnt;
+                    cw[e][0] = on ? en.c.a : 0u; cw[e][1] = on ? en.c.b : 0u; cw[e][2] = on ? en.c.c : 0u; cw[e][3] = on ? en.c.d : 0u;
+                }
+                u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
+                                {f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]}};
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    u64 a64[8];
+                    f8::pin(fp[0]);
+                    phase<kPrioHeavy>(fp[1]);
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {           // up to 4 products of < 2^62 plus the 31-bit running value
+                        const int k = 2 * h + (s >> 2), r = s & 3;
+                        u64 a = first ? 0ull : (u64)num[h][s];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) a += (u64)cw[e][k] * (u64)fp[e >> 1][4 * (e & 1) + r];
+                        a64[s] = a;
+                    }
+                    f8::reduce(num[h], a64);
+                }
+                first = false;
             }
+            if (first) { bcast(num[0], 0u); bcast(num[1], 0u); }
+            u32 term[2][8];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int h = 0; h < 2; h++) {
+                // num - (A y + B)
+                u32 b8[8], t8[8], nb[8], nq[8];
 #pragma unroll
                 for (int s = 0; s < 8; s++) {
-                    u64 a = (u64)num[k][s];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) a += (u64)cw[e][k] * (u64)f[e][s];
-                    num[k][s] = m31_reduce_u64(a);
+                    const int k = 2 * h + (s >> 2);
+                    b8[s] = k == 0 ? bc.B.a : k == 1 ? bc.B.b : k == 2 ? bc.B.c : bc.B.d;
+                    t8[s] = ay[k + 4 * half];
                 }
-        }
-        // denominator, linear in the point: (Pr.x - x) Pi.y - (Pr.y - y) Pi.x = (Pr.x Pi.y - Pr.y Pi.x) - x Pi.y + y Pi.x, i.e. per
-        // coordinate C0 + x (P - Pi.y) + y Pi.x: two multiply-adds on top of a per-batch constant and one reduction
-        const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));
-        const u32 npya = M31_P - bc.piy.a, npyb = M31_P - bc.piy.b;
-        cm31 den[8], pre[8];
-        qm31 numq[8];
+                f8::sub(nb, num[h], b8);
+                f8::addsub<(~kSignY) & 0xFFu>(nq, nb, t8);       // minus (+ A y) on the rows with +y, plus on the rows with -y
+                // term = (nA + nB i) (ir + ii i): [re of the 4 rows | im of the 4 rows]
+                u32 U[8], V[8], W[8], Z[8];
+                const u32 P = vgpr_P();
+                f8::done();
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            numq[s] = qm31_sub({num[0][s], num[1][s], num[2][s], num[3][s]}, qm31_add(qm31_mul_m31(bc.A, pt[s].y), bc.B));
-            cm31 d;
-            d.a = m31_reduce_u64((u64)c0.a + (u64)pt[s].x * npya + (u64)pt[s].y * bc.pix.a);
-            d.b = m31_reduce_u64((u64)c0.b + (u64)pt[s].x * npyb + (u64)pt[s].y * bc.pix.b);
-            if (cm31_is_zero(d)) { zero = true; d = {1u, 0u}; }
-            den[s] = d;
-            pre[s] = s == 0 ? d : cm31_mul(pre[s - 1], d);
-        }
-        cm31 cur = cm31_inv(pre[7]);
+                for (int s = 0; s < 8; s++) {
+                    const int r = 4 * half + (s & 3);
+                    U[s] = nq[s & 3]; W[s] = nq[4 + (s & 3)];
+                    V[s] = s < 4 ? ir[r] : ii[r];
+                    Z[s] = s < 4 ? P - ii[r] : ir[r];
+                }
+                u64 a64[8];
+                f8::pin(U); f8::pin(V); f8::pin(W);
+                phase<kPrioHeavy>(Z);
+                f8::mul64(a64, U, V); f8::mad(a64, W, Z);
+                f8::reduce<false>(term[h], a64);
+            }
+            f8::done();
+            if (SINGLE) {
 #pragma unroll
-        for (int s = 7; s >= 0; s--) {
-            cm31 dinv = s == 0 ? cur : cm31_mul(pre[s - 1], cur);
-            cur = cm31_mul(cur, den[s]);
-            const qm31 term = qm31_mul_cm31(numq[s], dinv);
-            acc[s] = b == 0 ? term : qm31_add(qm31_mul(acc[s], bc.coeff), term);     // the accumulator is zero before the first batch
+                for (int h = 0; h < 2; h++) {
+                    gstore4(out.p[2 * h] + row0 + 4 * half, make_uint4(term[h][0], term[h][1], term[h][2], term[h][3]));
+                    gstore4(out.p[2 * h + 1] + row0 + 4 * half, make_uint4(term[h][4], term[h][5], term[h][6], term[h][7]));
+                }
+            } else if (b == 0) {              // the accumulator is zero before the first batch
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[SINGLE ? 0 : k][4 * half + r] = term[k >> 1][4 * (k & 1) + r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int s = 4 * half + r;
+                    const qm31 m = qm31_mul({acc[0][s], acc[SINGLE ? 0 : 1][s], acc[SINGLE ? 0 : 2][s], acc[SINGLE ? 0 : 3][s]}, bc.coeff);
+                    acc[0][s] = m31_add(m.a, term[0][r]); acc[SINGLE ? 0 : 1][s] = m31_add(m.b, term[0][4 + r]);
+                    acc[SINGLE ? 0 : 2][s] = m31_add(m.c, term[1][r]); acc[SINGLE ? 0 : 3][s] = m31_add(m.d, term[1][4 + r]);
+                }
+            }
         }
     }
     if (zero) atomicOr(flag, 1u);
-    gstore4(out.p[0] + row0, make_uint4(acc[0].a, acc[1].a, acc[2].a, acc[3].a));
-    gstore4(out.p[0] + row0 + 4, make_uint4(acc[4].a, acc[5].a, acc[6].a, acc[7].a));
-    gstore4(out.p[1] + row0, make_uint4(acc[0].b, acc[1].b, acc[2].b, acc[3].b));
-    gstore4(out.p[1] + row0 + 4, make_uint4(acc[4].b, acc[5].b, acc[6].b, acc[7].b));
-    gstore4(out.p[2] + row0, make_uint4(acc[0].c, acc[1].c, acc[2].c, acc[3].c));
-    gstore4(out.p[2] + row0 + 4, make_uint4(acc[4].c, acc[5].c, acc[6].c, acc[7].c));
-    gstore4(out.p[3] + row0, make_uint4(acc[0].d, acc[1].d, acc[2].d, acc[3].d));
-    gstore4(out.p[3] + row0 + 4, make_uint4(acc[4].d, acc[5].d, acc[6].d, acc[7].d));
+    if (!SINGLE) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            gstore4(out.p[k] + row0, make_uint4(acc[SINGLE ? 0 : k][0], acc[SINGLE ? 0 : k][1], acc[SINGLE ? 0 : k][2], acc[SINGLE ? 0 : k][3]));
+            gstore4(out.p[k] + row0 + 4, make_uint4(acc[SINGLE ? 0 : k][4], acc[SINGLE ? 0 : k][5], acc[SINGLE ? 0 : k][6], acc[SINGLE ? 0 : k][7]));
+        }
+    }
 }
 
 // Any log_size (used for log_size < 3): one row per lane, the reference's formulation verbatim.
@@ -232,8 +318,12 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         host::point(1u << 29, &qx, &qy);   // order-4 point
         cpoint q4 = {qx, qy};
         size_t n_threads = (size_t)1 << (log_size - 3);
-        hipLaunchKernelGGL(k_quotients8, dim3(ceil_div(n_threads, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu,
-                           log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_win, q4, c.flag);
+        if (n_batches == 1)
+            hipLaunchKernelGGL(k_quotients8<true>, dim3(ceil_div(n_threads, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu,
+                               log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_win, q4, c.flag);
+        else
+            hipLaunchKernelGGL(k_quotients8<false>, dim3(ceil_div(n_threads, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu,
+                               log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_win, q4, c.flag);
     } else {
         size_t N = (size_t)1 << log_size;
         hipLaunchKernelGGL(k_quotients_row, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size,
