@@ -249,6 +249,29 @@ typedef struct {
 } tstwo_decommit_request;
 int tstwo_merkle_decommit_many(const tstwo_decommit_request *reqs, size_t n_reqs, uint32_t *queried_values,
                                uint8_t *hash_witness, uint32_t *column_witness, size_t *counts, size_t totals[3]);
+/* FriProver.decommit_on_queries (fri.ts:768-785) for a whole FRI proof in ONE round trip: per layer the position logic of
+ * computeDecommitmentPositionsAndWitnessEvals (fri.ts:346-384), the witness evaluations, and the Merkle decommitment of the
+ * layer's tree at those positions (the queried values are not part of a FriLayerProof, fri.ts:262-269).
+ * layers[0] = the first layer: n_evals circle evaluations (possibly of several sizes) under one tree, each queried at the
+ * positions folded to its own size (fri.ts:470-480) with fold step `first_fold_step` (CIRCLE_TO_LINE_FOLD_STEP = 1);
+ * layers[1..] = the inner layers: one line evaluation each, queried at the positions folded so far, with `fold_step`
+ * (FOLD_STEP = 1).  cols: host array of 4 * n_evals device pointers — the coordinate columns of each evaluation in the order
+ * the tree was committed with (tstwo_merkle_commit).  queries: ascending distinct positions in [0, 2^log_domain_size).
+ * Outputs (host), concatenated layer by layer: witness_evals (4 words per evaluation, in the order fri.ts:346-384 pushes
+ * them; first layer: evaluation by evaluation), hash_witness (32 bytes each), column_witness; counts[3r..3r+2] = (witness
+ * evaluations, hashes, column-witness words) of layer r; totals[3] is in/out (capacities / required sizes) like
+ * tstwo_merkle_decommit_many.  commitments (host, n_layers * 32 bytes, may be NULL): every tree's root
+ * (FriLayerProof.commitment) in the same round trip. */
+typedef struct {
+    const uint8_t *layers;                 /* device: the layer's tstwo_merkle_commit buffer */
+    uint32_t max_log;                      /* log size of the tree */
+    const uint32_t *const *cols;           /* host array of 4 * n_evals device column pointers */
+    const uint32_t *eval_logs;             /* log size of each evaluation */
+    size_t n_evals;
+} tstwo_fri_layer;
+int tstwo_fri_decommit(const tstwo_fri_layer *layers, size_t n_layers, const uint64_t *queries, size_t n_queries,
+                       uint32_t log_domain_size, uint32_t first_fold_step, uint32_t fold_step, uint32_t *witness_evals,
+                       uint8_t *hash_witness, uint32_t *column_witness, uint8_t *commitments, size_t *counts, size_t totals[3]);
 /* Gather for MerkleProver.decommit (vcs/prover.ts:32-109): item i = `words` consecutive uint32 words starting at
  * word index idx[i]*words of the device buffer srcs[i] (a column: words = 1; a layer of digests: words = 8).
  * Results land contiguously in host_out (n_items * words words).  srcs / idx are host arrays.  Synchronises. */

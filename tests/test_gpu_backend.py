@@ -1214,3 +1214,50 @@ def test_c_abi_collective_world_of_one():
             HipComm(0, 1, lambda uid: uid)
     finally:
         comm.close()
+
+
+# ---------------------------------------------------------------- tstwo_fri_decommit: the whole FRI opening in one library call
+@pytest.mark.parametrize("shape", [([8], 2, 5), ([10, 8], 2, 17), ([9, 7, 5], 1, 40), ([12], 3, 3)], ids=str)
+def test_fri_decommit_in_library_equals_host_walk(shape):
+    """FriProver.decommit_on_queries (ONE tstwo_fri_decommit call: fri.ts:346-384 position logic + witness evaluations + every
+    tree's Merkle decommitment + the roots) returns byte for byte what the round-2 path returns (positions planned in Python,
+    a gather and tstwo_merkle_decommit_many) — and the verifier accepts it."""
+    log_degs, blow, n_queries = shape
+    cfg = T.FriConfig(1, blow, n_queries)
+    cols, tw = [], None
+    for i, ld in enumerate(log_degs):
+        c, t = _secure_low_degree_eval(ld, blow, 7000 + 13 * i)
+        cols.append(c)
+        tw = tw or t
+    prover = T.FriProver.commit(T.Blake2sChannel(), cfg, cols, tw)
+    rng = np.random.default_rng(sum(log_degs) + n_queries)
+    max_log = max(log_degs) + blow
+    for trial in range(3):
+        pos = sorted(set(int(x) for x in rng.integers(0, 1 << max_log, size=n_queries)))
+        if trial == 2:
+            pos = [0, 1, (1 << max_log) - 1]                       # coset mates and the last row
+        queries = T.Queries(pos, max_log)
+        a, b = prover.decommit_on_queries(queries), prover.decommit_on_queries_host_walk(queries)
+        for la, lb in zip([a.first_layer] + a.inner_layers, [b.first_layer] + b.inner_layers):
+            assert [w.tup() for w in la.fri_witness] == [w.tup() for w in lb.fri_witness]
+            assert la.decommitment.hashWitness == lb.decommitment.hashWitness
+            assert [v.value for v in la.decommitment.columnWitness] == [v.value for v in lb.decommitment.columnWitness]
+            assert la.commitment == lb.commitment
+        assert len(a.inner_layers) == len(b.inner_layers)
+
+
+def test_fri_decommit_capi_errors():
+    col, tw = _secure_low_degree_eval(6, 2, 7100)
+    prover = T.FriProver.commit(T.Blake2sChannel(), T.FriConfig(1, 2, 4), [col], tw)
+    with pytest.raises(L.TstwoError, match="ascending and distinct"):
+        prover.decommit_on_queries(_RawQueries([5, 3], 8))
+    with pytest.raises(L.TstwoError, match="outside the domain"):
+        prover.decommit_on_queries(_RawQueries([1 << 8], 8))
+    assert prover.decommit_on_queries(T.Queries([], 8)).first_layer.fri_witness == []
+
+
+class _RawQueries:
+    """positions handed to the library unchecked (T.Queries validates them itself)"""
+
+    def __init__(self, positions, log_domain_size):
+        self.positions, self.log_domain_size = positions, log_domain_size

@@ -346,6 +346,48 @@ export class HipMerkleProver {
   }
 }
 
+/** One committed FRI layer as tstwo_fri_decommit sees it: the tree and the evaluations under it (first layer: the circle
+ *  evaluations, possibly of several sizes; inner layers: one line evaluation). */
+export interface HipFriLayer { tree: HipMerkleProver; evaluations: readonly HipSecureColumn[]; }
+export interface HipFriLayerProof { friWitness: QM31[]; hashWitness: Blake2sHash[]; columnWitness: M31[]; commitment: Blake2sHash; }
+/** FriProver.decommit_on_queries (fri.ts:768-785) in ONE library call: per layer the position logic of
+ *  computeDecommitmentPositionsAndWitnessEvals (fri.ts:346-384), the witness evaluations, the Merkle decommitment of the layer's
+ *  tree and its root.  `queries`: ascending distinct positions in [0, 2^logDomainSize). */
+export function friDecommit(layers: readonly HipFriLayer[], queries: readonly number[], logDomainSize: number,
+                            firstFoldStep = 1, foldStep = 1): HipFriLayerProof[] {
+  const n = layers.length, nq = queries.length;
+  const desc = new BigUint64Array(5 * n);          // packed tstwo_fri_layer structs
+  const keep: unknown[] = [];
+  let totalEvals = 0, capH = 1;
+  layers.forEach((l, r) => {
+    const cols = ptrs(l.evaluations.flatMap((e) => e.columns.map((c) => c.dev)));
+    const logs = u32s(l.evaluations.map((e) => Math.log2(e.len())));
+    keep.push(cols, logs);
+    desc[5 * r] = l.tree.rootDev(); desc[5 * r + 1] = BigInt(l.tree.maxLog); desc[5 * r + 2] = BigInt(ptr(cols));
+    desc[5 * r + 3] = BigInt(ptr(logs)); desc[5 * r + 4] = BigInt(l.evaluations.length);
+    totalEvals += l.evaluations.length;
+    capH += 4 * nq * (l.tree.maxLog + 1);
+  });
+  const capE = Math.max(1, 2 * nq * totalEvals), capW = Math.max(1, 8 * nq * totalEvals);
+  const evals = new Uint32Array(4 * capE), hashes = new Uint8Array(32 * capH), colWit = new Uint32Array(capW), roots = new Uint8Array(32 * n);
+  const counts = new BigUint64Array(3 * n), totals = BigUint64Array.from([BigInt(capE), BigInt(capH), BigInt(capW)]);
+  check(hip.tstwo_fri_decommit(ptr(desc), BigInt(n), ptr(BigUint64Array.from(queries.map(BigInt))), BigInt(nq), logDomainSize, firstFoldStep, foldStep,
+    ptr(evals), ptr(hashes), ptr(colWit), ptr(roots), ptr(counts), ptr(totals)));
+  const out: HipFriLayerProof[] = [];
+  let e0 = 0, h0 = 0, w0 = 0;
+  for (let r = 0; r < n; r++) {
+    const [ne, nh, nw] = [Number(counts[3 * r]), Number(counts[3 * r + 1]), Number(counts[3 * r + 2])];
+    out.push({
+      friWitness: Array.from({ length: ne }, (_, i) => QM31.from_u32_unchecked(evals[4 * (e0 + i)]!, evals[4 * (e0 + i) + 1]!, evals[4 * (e0 + i) + 2]!, evals[4 * (e0 + i) + 3]!)),
+      hashWitness: Array.from({ length: nh }, (_, i) => new Blake2sHash(hashes.slice(32 * (h0 + i), 32 * (h0 + i) + 32))),
+      columnWitness: Array.from(colWit.subarray(w0, w0 + nw), (v) => M31.from_u32_unchecked(v)),
+      commitment: new Blake2sHash(roots.slice(32 * r, 32 * r + 32)),
+    });
+    e0 += ne; h0 += nh; w0 += nw;
+  }
+  return out;
+}
+
 /** The one exchange of a column-sharded prover (SURVEY.md 8e; include/tstwo_hip.h "multi-GPU"): one Bun process per GPU,
  *  the RCCL unique id handed from rank 0 to the others by any host channel (a file, a socket, an env variable). */
 export class HipComm {

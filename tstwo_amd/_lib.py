@@ -36,6 +36,11 @@ class DecommitRequest(C.Structure):
                 ("n_query_sets", C.c_size_t)]
 
 
+class FriLayer(C.Structure):
+    """tstwo_fri_layer (include/tstwo_hip.h)."""
+    _fields_ = [("layers", vp), ("max_log", C.c_uint32), ("cols", C.POINTER(vp)), ("eval_logs", u32p), ("n_evals", C.c_size_t)]
+
+
 _SIGS = {
     "tstwo_init": [C.c_int],
     "tstwo_shutdown": [],
@@ -106,6 +111,8 @@ _SIGS = {
                               C.POINTER(C.c_size_t), C.c_size_t, u32p, C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_size_t),
                               u32p, C.POINTER(C.c_size_t)],
     "tstwo_merkle_decommit_many": [C.POINTER(DecommitRequest), C.c_size_t, u32p, u8p, u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
+    "tstwo_fri_decommit": [C.POINTER(FriLayer), C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u8p, u32p,
+                           u8p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "tstwo_gather_words": [C.POINTER(vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_size_t, u32p],
     "tstwo_quotients_accumulate_samples": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p, u32p, u32p, P4],
     "tstwo_quotients_accumulate": [C.c_uint32, C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_size_t, u32p, u32p, u32p,

@@ -848,7 +848,9 @@ static int plan_decommit(const uint8_t *layers, u32 max_log, const u32 *const *c
 }
 
 // One upload of all request items, two launches (8-word digests, 1-word column values), one read-back.
-static int run_decommit(const DecommitLists &l, u32 *queried_values, uint8_t *hash_witness, u32 *column_witness) {
+// (the last n_extra entries of l.hashes go to `extra` instead of hash_witness: the roots of a FRI proof's trees)
+static int run_decommit(const DecommitLists &l, u32 *queried_values, uint8_t *hash_witness, u32 *column_witness, size_t n_extra = 0,
+                        uint8_t *extra = nullptr) {
     const size_t nh = l.hashes.size(), nq = l.queried.size(), nw = l.witness.size(), nv = nq + nw;
     if (nh + nv == 0) return TSTWO_OK;
     Context &c = ctx();
@@ -871,7 +873,8 @@ static int run_decommit(const DecommitLists &l, u32 *queried_values, uint8_t *ha
     std::vector<u32> host(out_words);
     rc = small_d2h(host.data(), d_out, out_words * sizeof(u32));
     if (rc) return rc;
-    if (nh) memcpy(hash_witness, host.data(), 32 * nh);
+    if (nh - n_extra) memcpy(hash_witness, host.data(), 32 * (nh - n_extra));
+    if (n_extra) memcpy(extra, host.data() + 8 * (nh - n_extra), 32 * n_extra);
     if (nq) memcpy(queried_values, host.data() + 8 * nh, 4 * nq);
     if (nw) memcpy(column_witness, host.data() + 8 * nh + nq, 4 * nw);
     return TSTWO_OK;
@@ -918,6 +921,104 @@ int tstwo_merkle_decommit_many(const tstwo_decommit_request *reqs, size_t n_reqs
         (l.queried.size() && !queried_values) || (l.hashes.size() && !hash_witness) || (l.witness.size() && !column_witness))
         return set_error(TSTWO_ERR_BAD_ARG, "merkle decommit: output buffer too small (required counts returned)");
     return run_decommit(l, queried_values, hash_witness, column_witness);
+}
+
+// ---- FriProver.decommit_on_queries (fri.ts:768-785) in ONE call: the position logic of
+// computeDecommitmentPositionsAndWitnessEvals (fri.ts:346-384) for every layer, the Merkle walk of every layer's tree
+// (vcs/prover.ts:32-109, plan_decommit above) and ONE gather round trip for all witness evaluations, hash witnesses and
+// column witnesses of the proof.
+namespace {
+// Queries.fold (queries.ts:140-158): positions >> n, de-duplicated (the input is ascending, so is the output)
+void fold_queries(std::vector<uint64_t> &q, u32 n) {
+    size_t w = 0;
+    for (size_t i = 0; i < q.size(); i++) {
+        const uint64_t v = q[i] >> n;
+        if (w == 0 || q[w - 1] != v) q[w++] = v;
+    }
+    q.resize(w);
+}
+// fri.ts:346-384: every position of the folding cosets the queries touch (-> Merkle query set), and those among them the
+// verifier cannot compute itself (-> witness evaluations)
+void decommitment_positions(const std::vector<uint64_t> &q, u32 fold_step, std::vector<uint64_t> &positions, std::vector<uint64_t> &witness) {
+    size_t i = 0;
+    while (i < q.size()) {
+        const uint64_t coset = q[i] >> fold_step, start = coset << fold_step;
+        const size_t first = i;
+        while (i < q.size() && (q[i] >> fold_step) == coset) i++;
+        size_t k = first;
+        for (uint64_t pos = start; pos < start + ((uint64_t)1 << fold_step); pos++) {
+            positions.push_back(pos);
+            if (k < i && q[k] == pos) { k++; continue; }       // the verifier can calculate this one
+            witness.push_back(pos);
+        }
+    }
+}
+}  // namespace
+
+int tstwo_fri_decommit(const tstwo_fri_layer *fri_layers, size_t n_layers, const uint64_t *queries, size_t n_queries, u32 log_domain_size,
+                       u32 first_fold_step, u32 fold_step, u32 *witness_evals, uint8_t *hash_witness, u32 *column_witness, uint8_t *commitments,
+                       size_t *counts, size_t totals[3]) {
+    TSTWO_REQUIRE_READY();
+    if ((n_layers && (!fri_layers || !counts)) || (n_queries && !queries) || !totals) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: null argument");
+    if (log_domain_size > 31 || first_fold_step > 31 || fold_step > 31 || fold_step == 0) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: log size / fold step out of range");
+    std::vector<uint64_t> q(queries, queries + n_queries);
+    for (size_t i = 0; i < n_queries; i++) {
+        if (q[i] >> log_domain_size) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: query position outside the domain");
+        if (i && q[i - 1] >= q[i]) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: query positions must be ascending and distinct");
+    }
+    DecommitLists l;
+    std::vector<GatherItem> evals;            // one item per coordinate word of a witness evaluation, layer by layer
+    std::vector<std::vector<uint64_t>> pos_sets;
+    for (size_t r = 0; r < n_layers; r++) {
+        const tstwo_fri_layer &fl = fri_layers[r];
+        if (!fl.layers || !fl.n_evals || !fl.cols || !fl.eval_logs) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: null argument");
+        TSTWO_REQUIRE_TABLE(fl.cols, 4 * fl.n_evals);
+        const size_t h0 = l.hashes.size(), w0 = l.witness.size(), e0 = evals.size();
+        // Merkle query sets of this tree: one per distinct evaluation size (first layer: the circle evaluations folded to their
+        // own size, get_query_positions_by_log_size fri.ts:470-480; inner layers: the one line evaluation)
+        pos_sets.clear();
+        std::vector<u32> set_logs;
+        std::vector<u32> col_logs(4 * fl.n_evals);
+        const u32 step = r == 0 ? first_fold_step : fold_step;
+        for (size_t e = 0; e < fl.n_evals; e++) {
+            const u32 lg = fl.eval_logs[e];
+            if (lg > log_domain_size || lg > fl.max_log) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: evaluation larger than its tree / the query domain");
+            if (r > 0 && (fl.n_evals != 1 || lg != fl.max_log)) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: an inner layer commits one line evaluation");
+            for (int k = 0; k < 4; k++) col_logs[4 * e + k] = lg;
+            std::vector<uint64_t> cq = q;
+            if (r == 0) fold_queries(cq, log_domain_size - lg);
+            else if (cq.size() && (cq.back() >> lg)) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: layer sizes do not follow the fold steps");
+            std::vector<uint64_t> pos, wit;
+            decommitment_positions(cq, step, pos, wit);
+            if (pos.size() && (pos.back() >> lg)) return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: fold step larger than the evaluation");
+            for (uint64_t p : wit)
+                for (int k = 0; k < 4; k++) evals.push_back({fl.cols[4 * e + k], p});
+            bool seen = false;
+            for (u32 sl : set_logs) seen = seen || sl == lg;
+            if (!seen) { set_logs.push_back(lg); pos_sets.push_back(std::move(pos)); }
+        }
+        std::vector<const uint64_t *> qp(pos_sets.size());
+        std::vector<size_t> qn(pos_sets.size());
+        for (size_t k = 0; k < pos_sets.size(); k++) { qp[k] = pos_sets[k].data(); qn[k] = pos_sets[k].size(); }
+        const size_t q0 = l.queried.size();
+        int rc = plan_decommit(fl.layers, fl.max_log, fl.cols, col_logs.data(), 4 * fl.n_evals, set_logs.data(), qp.data(), qn.data(), pos_sets.size(), l);
+        if (rc) return rc;
+        l.queried.resize(q0);                  // the queried values themselves are not part of a FRI layer proof (fri.ts:262-269)
+        counts[3 * r] = (evals.size() - e0) / 4;
+        counts[3 * r + 1] = l.hashes.size() - h0;
+        counts[3 * r + 2] = l.witness.size() - w0;
+        // the next layer is queried at the folded positions (fri.ts:776-783)
+        fold_queries(q, r == 0 ? first_fold_step : fold_step);
+    }
+    const size_t cap_e = totals[0], cap_h = totals[1], cap_w = totals[2];
+    totals[0] = evals.size() / 4; totals[1] = l.hashes.size(); totals[2] = l.witness.size();
+    if (totals[0] > cap_e || totals[1] > cap_h || totals[2] > cap_w || (totals[0] && !witness_evals) || (totals[1] && !hash_witness) ||
+        (totals[2] && !column_witness))
+        return set_error(TSTWO_ERR_BAD_ARG, "fri decommit: output buffer too small (required counts returned)");
+    l.queried = evals;                         // travel as the "queried" 1-word items of the shared gather
+    if (commitments)                           // the trees' roots (FriLayerProof.commitment) ride along: digest 0 of every layers buffer
+        for (size_t r = 0; r < n_layers; r++) l.hashes.push_back({(const u32 *)fri_layers[r].layers, 0});
+    return run_decommit(l, witness_evals, hash_witness, column_witness, commitments ? n_layers : 0, commitments);
 }
 
 // Device-resident Blake2sChannel (state: 10 words = digest[8], n_challenges, n_sent).  root: 32 bytes in device memory

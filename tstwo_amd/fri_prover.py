@@ -124,6 +124,30 @@ class LinePoly:
     intoOrderedCoefficients, fromOrderedCoefficients = into_ordered_coefficients, from_ordered_coefficients
 
 
+class QM31Rows:
+    """A read-only sequence of QM31 over a (k, 4) uint32 array: the witness evaluations of a FRI layer as they came back from
+    the device.  Elements become QM31 objects when they are looked at (the verifier, a serialiser), not when the proof is
+    assembled — 600 witness evaluations of a 40-query proof cost 7 host objects each otherwise."""
+    __slots__ = ("rows",)
+
+    def __init__(self, rows):
+        self.rows = rows
+
+    def __len__(self): return len(self.rows)
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [QM31.from_u32_unchecked(*r) for r in self.rows[i]]
+        return QM31.from_u32_unchecked(*self.rows[i])
+    def __iter__(self): return (QM31.from_u32_unchecked(*r) for r in self.rows)
+    def __setitem__(self, i, q): self.rows[i] = list(q.to_m31_array_values() if hasattr(q, "to_m31_array_values") else (*q.c0.tup(), *q.c1.tup()))
+    def pop(self, i=-1): return QM31.from_u32_unchecked(*self.rows.pop(i))
+    def append(self, q): self.rows.append([*q.c0.tup(), *q.c1.tup()])
+    def __eq__(self, o): return list(self) == list(o)
+    def __add__(self, o): return list(self) + list(o)
+    def __radd__(self, o): return list(o) + list(self)
+    def __repr__(self): return f"QM31Rows({list(self)!r})"
+
+
 @dataclass
 class FriLayerProof:
     """fri.ts:262-269."""
@@ -349,8 +373,55 @@ class FriProver:
         return self.decommit_on_queries(queries), by_log
 
     def decommit_on_queries(self, queries: Queries) -> FriProof:
-        """fri.ts:768-785.  The positions of every layer are planned first; then ONE gather fetches all witness evaluations
-        and ONE tstwo_merkle_decommit_many call decommits all trees (instead of three round trips per layer)."""
+        """fri.ts:768-785 in ONE library call (tstwo_fri_decommit): the position logic of fri.ts:346-384 for every layer, the
+        witness evaluations and every tree's decommitment come back from one gather round trip."""
+        import ctypes as C
+
+        import numpy as np
+        max_log = queries.log_domain_size
+        assert max_log == self.first_layer.max_column_log_size()
+        layers = [self.first_layer] + list(self.inner_layers)
+        n = len(layers)
+        descs = (L.FriLayer * n)()
+        keep = []
+        total_evals = 0
+        for r, layer in enumerate(layers):
+            evs = layer.columns if r == 0 else [layer.evaluation]
+            colp = L.ptr_array([cc.ptr for e in evs for cc in e.values.columns])
+            logs = L.u32x([(e.domain.logSize() if r == 0 else e.domain().logSize()) for e in evs])
+            keep += [colp, logs]
+            tree = layer.merkle_tree
+            descs[r] = L.FriLayer(tree._buf.ptr, len(tree.layers) - 1, colp, logs, len(evs))
+            total_evals += len(evs)
+        nq = len(queries.positions)
+        qarr = (C.c_uint64 * max(nq, 1))(*queries.positions)
+        # capacities: a query touches one coset of 2^step positions per evaluation and layer; <= 2 hashes per level and position
+        cap_e = max(1, 2 * nq * total_evals)
+        cap_h = max(1, sum(4 * nq * (len(l.merkle_tree.layers)) for l in layers))
+        cap_w = max(1, 8 * nq * total_evals)
+        evals = np.empty(4 * cap_e, dtype=np.uint32)
+        hashes = np.empty(32 * cap_h, dtype=np.uint8)
+        colwit = np.empty(cap_w, dtype=np.uint32)
+        roots = np.empty(32 * n, dtype=np.uint8)
+        counts = (C.c_size_t * (3 * n))()
+        totals = (C.c_size_t * 3)(cap_e, cap_h, cap_w)
+        L.call("tstwo_fri_decommit", descs, n, qarr, nq, max_log, CIRCLE_TO_LINE_FOLD_STEP, FOLD_STEP, evals.ctypes.data_as(L.u32p),
+               hashes.ctypes.data_as(L.u8p), colwit.ctypes.data_as(L.u32p), roots.ctypes.data_as(L.u8p), counts, totals)
+        hb, rb = hashes.tobytes(), roots.tobytes()
+        ev = evals[:4 * totals[0]].reshape(-1, 4).tolist()
+        wl = colwit[:totals[2]].tolist()
+        proofs, e0, h0, w0 = [], 0, 0, 0
+        for r, layer in enumerate(layers):
+            ne, nh, nw = counts[3 * r], counts[3 * r + 1], counts[3 * r + 2]
+            dec = MerkleDecommitment([hb[32 * (h0 + i):32 * (h0 + i) + 32] for i in range(nh)], [M31(v) for v in wl[w0:w0 + nw]])
+            layer.merkle_tree._root = rb[32 * r:32 * r + 32]          # (what root() would read back: 32 bytes per tree)
+            proofs.append(FriLayerProof(QM31Rows(ev[e0:e0 + ne]), dec, layer.merkle_tree._root))
+            e0, h0, w0 = e0 + ne, h0 + nh, w0 + nw
+        return FriProof(proofs[0], proofs[1:], self.last_layer_poly)
+
+    def decommit_on_queries_host_walk(self, queries: Queries) -> FriProof:
+        """The round-2 path, kept to cross-check the in-library one: positions planned here (fri.ts:346-384), ONE gather for all
+        witness evaluations and ONE tstwo_merkle_decommit_many call for all trees."""
         plans = []                      # (tree, positions_by_log, merkle columns, [(SecureColumnByCoords, witness positions)])
         max_log = queries.log_domain_size
         assert max_log == self.first_layer.max_column_log_size()
