@@ -35,20 +35,33 @@ def run_configs(reps=10, no_cpu=False, emit_line=None):
     L.ensure_init()
     records = []
 
+    last_cold = [None]
+
     def timed(fn, reps=args.reps, warm=2):
+        """Steady-state time per call (ms): the GPU idles during the CPU-oracle legs between the kernels, and the part needs
+        40-75 ms of load before its clocks settle (DESIGN.md 4.1 "Clocks"), so after `warm` calls the first `reps` calls are
+        timed as the COLD figure (emit() records it as ms_cold), the kernel then runs for ~80 ms untimed, and the steady figure is
+        taken over >= 20 ms of back-to-back calls."""
+        def measure(k):
+            e0, e1 = L.Event(), L.Event()
+            L.sync()
+            e0.record()
+            for _ in range(k):
+                fn()
+            e1.record()
+            return e0.elapsed_ms(e1) / k
         for _ in range(warm):
             fn()
-        e0, e1 = L.Event(), L.Event()
-        L.sync()
-        e0.record()
-        for _ in range(reps):
+        cold = measure(reps)
+        last_cold[0] = cold
+        for _ in range(min(5000, int(80.0 / max(cold, 1e-3)) + 1)):
             fn()
-        e1.record()
-        return e0.elapsed_ms(e1) / reps
+        return measure(min(5000, max(reps, int(20.0 / max(cold, 1e-3)) + 1)))
 
     def emit(config, kernel, ms, algo_bytes, units, unit_name, cpu=None):
         gbps = algo_bytes / (ms * 1e-3) / 1e9
-        out = {"config": config, "kernel": kernel, "ms": round(ms, 5), "algorithmic_GB": round(algo_bytes / 1e9, 4),
+        out = {"config": config, "kernel": kernel, "ms": round(ms, 5), "ms_cold": round(last_cold[0], 5) if last_cold[0] else None,
+               "algorithmic_GB": round(algo_bytes / 1e9, 4),
                "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / HBM, 4), unit_name + "_per_s": units / (ms * 1e-3)}
         if cpu:
             out["cpu_oracle"] = cpu
@@ -94,13 +107,18 @@ def run_configs(reps=10, no_cpu=False, emit_line=None):
     ptr1 = L.ptr_array([col.ptr])
     half = dom.halfCoset.initial_index.value
     ms_e = timed(lambda: L.call("tstwo_cfft_evaluate", ptr1, 1, n, half, vp(tw.twiddles), n - 1))
+    cold_e = last_cold[0]
     ms_i = timed(lambda: L.call("tstwo_cfft_interpolate", ptr1, 1, n, half, vp(tw.itwiddles), n - 1))
+    cold_i = last_cold[0]
     cpu = None
     if not args.no_cpu:
         otw, _ = orc.precompute_twiddles(half, n - 1, inverse=False)
         cpu = cpu_time(lambda: orc.cfft_evaluate(col_h, n, half, otw, n - 1), n * (N // 2), "butterflies", "full column log 20")
+    last_cold[0] = cold_e
     emit(2, "cfft_evaluate 1 col log 20", ms_e, 8.0 * N, n * (N // 2), "butterflies", cpu)
+    last_cold[0] = cold_i
     emit(2, "cfft_interpolate 1 col log 20", ms_i, 8.0 * N, n * (N // 2), "butterflies")
+    last_cold[0] = None                       # the eval_at_point records below are wall-clock loops of their own
     # PolyOps.eval_at_point (a14): one point, one column log 22 (call = kernels + 16-byte read-back); 32 columns log 20 at one point
     import time as _t
     n22 = 22

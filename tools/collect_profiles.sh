@@ -1,6 +1,6 @@
 #!/bin/bash
 # Local: copy the summaries of gpurun_out/$TAG into profiles/ (tracked).
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/$TAG
 for f in bench.json configs.jsonl callers.jsonl cfft_pmc.json bench_kernel_summary.txt configs_kernel_summary.txt bench_kernel_stats.csv sq_counters.json; do
   [ $(wc -c < $O/$f 2>/dev/null || echo 0) -gt 200 ] && cp $O/$f profiles/${TAG}_$f
