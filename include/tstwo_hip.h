@@ -185,6 +185,26 @@ int tstwo_fri_fold_line_dev(const uint32_t *const in[4], uint32_t log_n, const u
                             const uint32_t *alpha_dev, uint32_t *const out[4]);
 int tstwo_fri_fold_circle_into_line_dev(uint32_t *const dst[4], size_t dst_len, const uint32_t *const src[4],
                                         uint32_t log_n, const uint32_t *itw, uint32_t tw_log, const uint32_t *alpha_dev);
+/* FriProver.commit's whole layer loop (commitInnerLayers, fri.ts:676-716, with the Merkle / channel wiring of the Rust text) in
+ * ONE call, enqueued on the library's stream with nothing read back: a tree over the coordinate columns of every circle
+ * evaluation (first layer), then per line layer: mix its root and draw alpha on the device channel
+ * (tstwo_channel_mix_root_draw_felt), fold (tstwo_fri_fold_*_dev), commit the folded evaluation — until the evaluation has
+ * 2^log_last_layer_size rows.
+ * circle_cols: host array of 4 * n_columns device pointers (coordinate columns of the circle evaluations, canonic domains whose
+ * half cosets are doublings of the tree's root — the wrapper checks, as for tstwo_fri_fold_circle_into_line); col_logs: their
+ * log sizes, strictly decreasing ("column sizes not decreasing" otherwise), each >= 3.  chan: the device channel state
+ * (10 words); alphas: device, 4 words per drawn alpha (16-byte aligned, alphas_cap entries >= number of trees).
+ * Outputs: *first_tree = the first layer's tree; out[0 .. *n_out - 2] = the inner layers (evaluation + tree, largest first);
+ * out[*n_out - 1] = the last layer's evaluation (layers = NULL), which the caller interpolates (fri.ts:718-754).  Every
+ * buffer returned is a tstwo_malloc block the CALLER owns (tstwo_free); on failure nothing is returned and nothing leaks. */
+typedef struct {
+    uint32_t log_size;                     /* the line evaluation has 2^log_size rows */
+    uint32_t *cols[4];                     /* device: its coordinate columns */
+    uint8_t *layers;                       /* device: the tree committed over them (tstwo_merkle_commit layout), or NULL */
+} tstwo_fri_layer_out;
+int tstwo_fri_commit_layers(const uint32_t *const *circle_cols, const uint32_t *col_logs, size_t n_columns, const uint32_t *itw,
+                            uint32_t tw_log, uint32_t log_last_layer_size, uint32_t *chan, uint32_t *alphas, size_t alphas_cap,
+                            uint8_t **first_tree, tstwo_fri_layer_out *out, size_t out_cap, size_t *n_out);
 /* Blake2sChannel on the device (channel/blake2.ts:25-224; Rust draw semantics).  chan = 10 words of device memory:
  * digest[8], n_challenges, n_sent (upload the host channel's state, download it back when done).
  * root != NULL: mix_root (vcs/blake2_merkle.ts:28-31) of the 32 bytes at `root` (device memory, e.g. byte 0 of a

@@ -1261,3 +1261,41 @@ class _RawQueries:
 
     def __init__(self, positions, log_domain_size):
         self.positions, self.log_domain_size = positions, log_domain_size
+
+
+def test_fri_commit_layers_capi_matches_host_loop_and_reports_errors(monkeypatch):
+    """tstwo_fri_commit_layers (the whole commit loop in one call) against the per-layer calls of round 2 (same device
+    transcript): identical trees, evaluations, last-layer polynomial and channel state, for one and for mixed-size columns; bad
+    arguments come back as errors and leak nothing."""
+    for log_degs in ([9], [10, 8, 7]):
+        cfg = T.FriConfig(2, 2, 5)
+        cols = [_secure_low_degree_eval(ld, 2, 8100 + ld)[0] for ld in log_degs]
+        tw = _secure_low_degree_eval(log_degs[0], 2, 8100 + log_degs[0])[1]
+        ch_a, ch_b = T.Blake2sChannel(), T.Blake2sChannel()
+        a = T.FriProver.commit(ch_a, cfg, cols, tw)
+        monkeypatch.setenv("TSTWO_FRI_COMMIT_HOST_LOOP", "1")
+        b = T.FriProver.commit(ch_b, cfg, cols, tw)
+        monkeypatch.delenv("TSTWO_FRI_COMMIT_HOST_LOOP")
+        assert ch_a.digest() == ch_b.digest()
+        assert a.first_layer.merkle_tree.root() == b.first_layer.merkle_tree.root()
+        assert len(a.inner_layers) == len(b.inner_layers) > 0
+        for la, lb in zip(a.inner_layers, b.inner_layers):
+            assert la.merkle_tree.root() == lb.merkle_tree.root()
+            assert la.evaluation.domain().logSize() == lb.evaluation.domain().logSize()
+            for ca, cb in zip(la.evaluation.values.to_numpy(), lb.evaluation.values.to_numpy()):
+                assert (ca == cb).all()
+        assert [c.tup() for c in a.last_layer_poly.coeffs] == [c.tup() for c in b.last_layer_poly.coeffs]
+    # errors through the C ABI
+    col, tw = _secure_low_degree_eval(6, 2, 8200)
+    ptrs4 = L.ptr_array([c.ptr for c in col.values.columns] * 2)
+    chan, alphas = L.DeviceBuffer(64), L.DeviceBuffer(16 * 16)
+    outs, n_out, first = (L.FriLayerOut * 16)(), C.c_size_t(0), L.vp()
+    args = lambda logs, n, last, cap: (ptrs4, L.u32x(logs), n, C.c_void_p(tw.itwiddles.ptr), tw.log_size, last, C.c_void_p(chan.ptr),
+                                       C.c_void_p(alphas.ptr), 16, C.byref(first), outs, cap, C.byref(n_out))
+    with pytest.raises(L.TstwoError, match="column sizes not decreasing"):
+        L.call("tstwo_fri_commit_layers", *args([8, 8], 2, 3, 16))
+    with pytest.raises(L.TstwoError, match="capacity too small"):
+        L.call("tstwo_fri_commit_layers", *args([8], 1, 3, 2))
+    with pytest.raises(L.TstwoError, match="no columns"):
+        L.call("tstwo_fri_commit_layers", *args([8], 0, 3, 16))
+    assert n_out.value == 0 and not first.value

@@ -18,14 +18,23 @@ L.init(0)
 rng = np.random.default_rng(0)
 
 
-def wall(fn, reps=3):
+def wall(fn, reps=3, spin_s=0.15):
+    """Steady-state wall time per call: the call itself runs for `spin_s` first (the part needs 40-75 ms of load before its
+    clocks settle, DESIGN 4.1 "Clocks" — three calls of a 3 ms caller sit inside that ramp and read 20-25 % high), then at least
+    `reps` calls and 30 ms are timed."""
     fn()
     L.sync()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        r = fn()
+    while time.perf_counter() - t0 < spin_s:
+        fn()
     L.sync()
-    return (time.perf_counter() - t0) / reps, r
+    t0 = time.perf_counter()
+    n = 0
+    while n < reps or time.perf_counter() - t0 < 0.03:
+        r = fn()
+        n += 1
+    L.sync()
+    return (time.perf_counter() - t0) / n, r
 
 
 def secure_low_degree(log_deg, blow):

@@ -7,7 +7,7 @@ import tstwo_amd as T
 from tstwo_amd import _lib as L
 L.init(0)
 rng = np.random.default_rng(0)
-for logd in (10, 14, 18, 20):
+for logd in (10, 14, 18, 20, 22):
     blow = 2
     domain = T.CanonicCoset(logd + blow).circleDomain()
     tw = T.precompute_twiddles(domain.halfCoset)
@@ -15,16 +15,24 @@ for logd in (10, 14, 18, 20):
     evs = T.evaluate_polynomials(polys, domain, tw)
     col = T.SecureEvaluation(domain, T.SecureColumnByCoords([e.values for e in evs]))
     cfg = T.FriConfig(2, blow, 20)
-    for dev in (True, False):
-        for _ in range(3):
+    for dev, host_loop in ((True, False), (True, True), (False, False)):
+        if host_loop:
+            os.environ["TSTWO_FRI_COMMIT_HOST_LOOP"] = "1"
+        else:
+            os.environ.pop("TSTWO_FRI_COMMIT_HOST_LOOP", None)
+        tw0 = time.perf_counter()
+        while time.perf_counter() - tw0 < 0.2:          # 200 ms of this very loop first: the clocks settle (DESIGN 4.1 "Clocks")
             T.FriProver.commit(T.Blake2sChannel(), cfg, [col], tw, device_channel=dev)
         L.sync(); t0 = time.perf_counter()
-        for _ in range(10):
+        for _ in range(20):
             T.FriProver.commit(T.Blake2sChannel(), cfg, [col], tw, device_channel=dev)
         L.sync()
-        print(f"log {logd + blow}: FriProver.commit device_channel={dev}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms")
+        tag = "device transcript, " + ("per-layer calls from the host" if host_loop else "tstwo_fri_commit_layers") if dev else "host transcript"
+        print(f"log {logd + blow}: FriProver.commit ({tag}): {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms", flush=True)
+    os.environ.pop("TSTWO_FRI_COMMIT_HOST_LOOP", None)
     plan = T.FriCommitPlan(cfg, [col], tw)
-    for _ in range(3):
+    tw0 = time.perf_counter()
+    while time.perf_counter() - tw0 < 0.2:
         plan.run(T.Blake2sChannel())
     L.sync(); t0 = time.perf_counter()
     for _ in range(10):

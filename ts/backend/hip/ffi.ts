@@ -80,6 +80,8 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   // n_cols, query_logs, queries, n_queries, n_query_sets) written into a BigUint64Array
   tstwo_merkle_decommit_many: { args: [P, u64, P, P, P, P, P], returns: i32 },
   // layers: a packed array of tstwo_fri_layer structs (5 x 8 bytes each: layers, max_log (u32, padded), cols, eval_logs, n_evals)
+  // out: a packed array of tstwo_fri_layer_out structs (6 x 8 bytes each: log_size (u32, padded), cols[4], layers); first_tree: one u64
+  tstwo_fri_commit_layers: { args: [P, P, u64, u64, u32, u32, u64, u64, u64, P, P, u64, P], returns: i32 },
   tstwo_fri_decommit: { args: [P, u64, P, u64, u32, u32, u32, P, P, P, P, P, P], returns: i32 },
   tstwo_gather_words: { args: [P, P, u32, u64, P], returns: i32 },
   tstwo_grind_blake2s: { args: [P, u32, u64, P], returns: i32 },

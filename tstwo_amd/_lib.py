@@ -41,6 +41,11 @@ class FriLayer(C.Structure):
     _fields_ = [("layers", vp), ("max_log", C.c_uint32), ("cols", C.POINTER(vp)), ("eval_logs", u32p), ("n_evals", C.c_size_t)]
 
 
+class FriLayerOut(C.Structure):
+    """tstwo_fri_layer_out (include/tstwo_hip.h)."""
+    _fields_ = [("log_size", C.c_uint32), ("cols", vp * 4), ("layers", vp)]
+
+
 _SIGS = {
     "tstwo_init": [C.c_int],
     "tstwo_shutdown": [],
@@ -111,6 +116,8 @@ _SIGS = {
                               C.POINTER(C.c_size_t), C.c_size_t, u32p, C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_size_t),
                               u32p, C.POINTER(C.c_size_t)],
     "tstwo_merkle_decommit_many": [C.POINTER(DecommitRequest), C.c_size_t, u32p, u8p, u32p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
+    "tstwo_fri_commit_layers": [C.POINTER(vp), u32p, C.c_size_t, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_size_t, C.POINTER(vp),
+                                C.POINTER(FriLayerOut), C.c_size_t, C.POINTER(C.c_size_t)],
     "tstwo_fri_decommit": [C.POINTER(FriLayer), C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u8p, u32p,
                            u8p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "tstwo_gather_words": [C.POINTER(vp), C.POINTER(C.c_uint64), C.c_uint32, C.c_size_t, u32p],
@@ -210,6 +217,13 @@ class DeviceBuffer:
         call("tstwo_malloc", C.byref(p), nbytes)
         self.ptr = p.value
         self.nbytes = nbytes
+
+    @staticmethod
+    def adopt(ptr: int, nbytes: int) -> "DeviceBuffer":
+        """Take ownership of a block the library allocated with tstwo_malloc and handed out (tstwo_fri_commit_layers)."""
+        b = DeviceBuffer.__new__(DeviceBuffer)
+        b.ptr, b.nbytes = ptr, nbytes
+        return b
 
     def free(self) -> None:
         if self.ptr:

@@ -18,7 +18,9 @@ struct Context {
     hipStream_t stream = nullptr;     // stream every launch goes to (own_stream or a borrowed one)
     cpoint *gen_pow2 = nullptr;       // device: GEN * 2^k, k = 0..30 (circle.ts:137)
     cpoint *gen_win = nullptr;        // device: 4 windows x 256 entries, [w][k] = (k * 2^(8w)) * GEN: idx * GEN in 3 point additions
-    u32 *flag = nullptr;              // device: error flag word (zero-inverse detection)
+    u32 *flag = nullptr;              // error flag word (zero-inverse detection) as the kernels address it: page-locked HOST memory mapped
+                                      // into the device when available (flag_host), else device memory
+    u32 *flag_host = nullptr;         // the same word as the host reads it after a stream synchronisation (no copy); nullptr: device flag
     u32 *scratch = nullptr;           // device scratch for reductions (decompose / eval_at_point)
     size_t scratch_bytes = 0;
     int n_cus = 256;
@@ -71,6 +73,9 @@ constexpr int kMaxColsPerLaunch = 64;    // CFFT / bit-reverse batch chunk
 // (`ext`), so that a batch of thousands of small columns is still ONE launch instead of one per 64 columns.
 struct ColPtrs { u32 *p[kMaxColsPerLaunch]; u32 *const *ext; };
 #ifdef __HIPCC__
+// The zero-inverse flag lives in host-coherent memory: a plain store of 1 (every writer writes the same value, and only when an
+// input WAS zero — the rare, failing case) is visible to the host once the kernel has completed.
+__device__ __forceinline__ void raise_flag(u32 *flag) { *(volatile u32 *)flag = 1u; }
 // (VALU issue model, phase<PRIO>(values...) and vgpr_P(): phase.cuh, included by m31.cuh)
 // Accesses to COLUMN data go through these: a column pointer comes out of a pointer table, so to the compiler it is a generic
 // address and a plain dereference is a flat_load / flat_store — vector-memory instructions that ALSO count on lgkmcnt, which

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_m31_batch_inverse(const u32 *__restrict
         x[j] = v;
         pre[j] = j == 0 ? v : m31_mul(pre[j - 1], v);
     }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     u32 cur = m31_inv(pre[K - 1]);
 #pragma unroll
     for (int j = K - 1; j >= 0; j--) {
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_cm31_batch_inverse(CSoa2 in, Soa2 out, 
         x[j] = v;
         pre[j] = j == 0 ? v : cm31_mul(pre[j - 1], v);
     }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     cm31 cur = cm31_inv(pre[K - 1]);
 #pragma unroll
     for (int j = K - 1; j >= 0; j--) {
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_v4(CSoa4 in, Soa4 ou
         if (qm31_is_zero(x[j])) { zero = true; x[j] = {1u, 0u, 0u, 0u}; }
         pre[j] = j == 0 ? x[j] : qm31_mul(pre[j - 1], x[j]);
     }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     qm31 cur = qm31_inv(pre[K - 1]);
     qm31 r[K];
 #pragma unroll
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_norm(CSoa4 in, Soa4 
 #pragma unroll
     for (int e = 0; e < 8; e++)
         if ((a[e] | b[e] | c[e] | d[e]) == 0) { zero = true; a[e] = 1u; }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     // operands: dmc2 = 2 (d - c mod P), d2 = 2d, b2 = 2b, nb = P - b, nc = P - c, nd2 = 2 (P - d)
     u32 dmc[8], dmc2[8], d2[8], b2[8], nb[8], nc[8], nd2[8];
     f8::sub(dmc, d, c);
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse(CSoa4 in, Soa4 out, 
         x[j] = v;
         pre[j] = j == 0 ? v : qm31_mul(pre[j - 1], v);
     }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     qm31 cur = qm31_inv(pre[K - 1]);
 #pragma unroll
     for (int j = K - 1; j >= 0; j--) {

@@ -398,6 +398,91 @@ int tstwo_fri_fold_circle_into_line_rows(u32 *const dst[4], const u32 *const src
     return TSTWO_OK;
 }
 
+// ---- FriProver.commit's layer loop in ONE call (commitInnerLayers, fri.ts:676-716, with the Merkle / channel wiring of the Rust
+// text): first-layer tree over every circle column's coordinate columns, then per layer: mix the root and draw alpha on the
+// device channel, fold, commit the folded evaluation.  The host-side loop did the same through ~10 C-ABI calls and a dozen
+// host objects per layer (40-50 us of host time each, more than the kernels of a layer below 2^16 rows take); here a layer
+// costs its launches only.  Everything is enqueued on the library's stream; nothing is read back.
+int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, size_t n_columns, const u32 *itw, u32 tw_log,
+                            u32 log_last_layer_size, u32 *chan, u32 *alphas, size_t alphas_cap, uint8_t **first_tree,
+                            tstwo_fri_layer_out *out, size_t out_cap, size_t *n_out) {
+    TSTWO_REQUIRE_READY();
+    if (!n_columns) return set_error(TSTWO_ERR_BAD_ARG, "no columns");
+    if (!circle_cols || !col_logs || !first_tree || !out || !n_out) return set_error(TSTWO_ERR_BAD_ARG, "fri commit: null argument");
+    TSTWO_REQUIRE_TABLE(circle_cols, 4 * n_columns);
+    TSTWO_REQUIRE_PTRS(itw, chan, alphas);
+    if (((uintptr_t)alphas) & 15) return set_error(TSTWO_ERR_BAD_ARG, "fold: alpha must be 16-byte aligned");
+    for (size_t i = 0; i < n_columns; i++) {
+        if (col_logs[i] < 3 || col_logs[i] > 31) return set_error(TSTWO_ERR_BAD_ARG, "fri commit: circle evaluations of log size 3..31");
+        if (i && col_logs[i - 1] <= col_logs[i]) return set_error(TSTWO_ERR_BAD_ARG, "column sizes not decreasing");
+    }
+    const u32 first_log = col_logs[0] - 1;          // CIRCLE_TO_LINE_FOLD_STEP = 1
+    if (log_last_layer_size > first_log) return set_error(TSTWO_ERR_BAD_ARG, "fri commit: last layer larger than the first line layer");
+    const size_t n_inner = first_log - log_last_layer_size;
+    if (out_cap < n_inner + 1 || alphas_cap < n_inner + 1) return set_error(TSTWO_ERR_BAD_ARG, "fri commit: output / alpha capacity too small");
+    *n_out = 0;
+    *first_tree = nullptr;
+    std::vector<void *> owned;                       // everything allocated here, released again if a step fails
+    auto fail = [&](int rc) { for (void *p : owned) (void)tstwo_free(p); *n_out = 0; *first_tree = nullptr; return rc; };
+    auto alloc = [&](void **p, size_t bytes) { int rc = tstwo_malloc(p, bytes); if (!rc) owned.push_back(*p); return rc; };
+    auto alloc_eval = [&](u32 *cols[4], u32 lg) {
+        for (int k = 0; k < 4; k++) { int rc = alloc((void **)&cols[k], sizeof(u32) << lg); if (rc) return rc; }
+        return (int)TSTWO_OK;
+    };
+    int rc;
+    // first layer: one tree over every column's coordinate columns (Rust FriFirstLayerProver::new), root -> channel -> alpha_0
+    {
+        std::vector<u32> logs(4 * n_columns);
+        for (size_t i = 0; i < n_columns; i++) for (int k = 0; k < 4; k++) logs[4 * i + k] = col_logs[i];
+        void *t = nullptr;
+        if ((rc = alloc(&t, tstwo_merkle_layers_bytes(col_logs[0])))) return fail(rc);
+        if ((rc = tstwo_merkle_commit(circle_cols, logs.data(), 4 * n_columns, (uint8_t *)t, nullptr))) return fail(rc);
+        *first_tree = (uint8_t *)t;
+    }
+    u32 *alpha = alphas;
+    if ((rc = tstwo_channel_mix_root_draw_felt(chan, *first_tree, alpha))) return fail(rc);
+    u32 *cur[4];
+    u32 cur_log = first_log;
+    if ((rc = alloc_eval(cur, cur_log))) return fail(rc);
+    for (int k = 0; k < 4; k++)
+        if ((rc = tstwo_zero(cur[k], sizeof(u32) << cur_log))) return fail(rc);
+    size_t nxt = 0;
+    auto fold_circle_in = [&]() {      // the circle column whose folded size is the current line layer joins it (same alpha)
+        const u32 *const src[4] = {circle_cols[4 * nxt], circle_cols[4 * nxt + 1], circle_cols[4 * nxt + 2], circle_cols[4 * nxt + 3]};
+        int r = tstwo_fri_fold_circle_into_line_dev(cur, (size_t)1 << cur_log, src, col_logs[nxt], itw, tw_log, alpha);
+        nxt++;
+        return r;
+    };
+    if ((rc = fold_circle_in())) return fail(rc);
+    size_t n = 0;
+    while (cur_log > log_last_layer_size) {
+        tstwo_fri_layer_out &o = out[n];
+        o.log_size = cur_log;
+        for (int k = 0; k < 4; k++) o.cols[k] = cur[k];
+        void *t = nullptr;
+        if ((rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log)))) return fail(rc);
+        o.layers = (uint8_t *)t;
+        const u32 lg4[4] = {cur_log, cur_log, cur_log, cur_log};
+        if ((rc = tstwo_merkle_commit(cur, lg4, 4, o.layers, nullptr))) return fail(rc);      // FriInnerLayerProver::new
+        alpha = alphas + 4 * (n + 1);
+        if ((rc = tstwo_channel_mix_root_draw_felt(chan, o.layers, alpha))) return fail(rc);
+        u32 *folded[4];
+        if ((rc = alloc_eval(folded, cur_log - 1))) return fail(rc);
+        if ((rc = tstwo_fri_fold_line_dev(cur, cur_log, itw, tw_log, alpha, folded))) return fail(rc);
+        for (int k = 0; k < 4; k++) cur[k] = folded[k];
+        cur_log--;
+        n++;
+        if (nxt < n_columns && col_logs[nxt] - 1 == cur_log)
+            if ((rc = fold_circle_in())) return fail(rc);
+    }
+    if (nxt != n_columns) return fail(set_error(TSTWO_ERR_BAD_ARG, "not all columns were consumed"));      // Rust: assert!(columns.is_empty())
+    out[n].log_size = cur_log;
+    for (int k = 0; k < 4; k++) out[n].cols[k] = cur[k];
+    out[n].layers = nullptr;                         // the last layer is interpolated, not committed (fri.ts:718-754)
+    *n_out = n + 1;
+    return TSTWO_OK;
+}
+
 int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32 lambda[4]) {
     TSTWO_REQUIRE_READY();
     if (n == 0) return set_error(TSTWO_ERR_BAD_ARG, "decompose: empty evaluation");

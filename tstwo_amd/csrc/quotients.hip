@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
             }
         }
     }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     if (!SINGLE) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) k_quotients_row(u32 half_initial, u32 log
         if (cm31_is_zero(d)) { zero = true; d = {1u, 0u}; }
         acc = qm31_add(qm31_mul(acc, bc.coeff), qm31_mul_cm31(num, cm31_inv(d)));
     }
-    if (zero) atomicOr(flag, 1u);
+    if (zero) raise_flag(flag);
     out.p[0][row] = acc.a; out.p[1][row] = acc.b; out.p[2][row] = acc.c; out.p[3][row] = acc.d;
 }
 

@@ -6,17 +6,18 @@ coordinate columns (device resident), the root is mixed into the channel, and th
 Layers never leave HBM between fold and commit; only 32-byte roots and the (tiny) last layer reach the host."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 from . import _lib as L
-from .backend import SecureColumnByCoords
+from .backend import HipColumn, SecureColumnByCoords
 from .channel import DeviceChannel
 from .circle import Coset, LineDomain, bit_reverse_index
 from .queries import Queries, get_query_positions_by_log_size
 from .fields import M31, P, QM31
 from .fri import CIRCLE_TO_LINE_FOLD_STEP, HipFriOps
 from .poly import LineEvaluation, SecureEvaluation, TwiddleTree
-from .vcs import MerkleDecommitment, MerkleProver
+from .vcs import DeviceHashLayer, MerkleDecommitment, MerkleProver
 
 FOLD_STEP = 1
 
@@ -308,7 +309,12 @@ class FriProver:
         if on_device:
             dch = DeviceChannel(channel)
             alphas = L.DeviceBuffer(16 * (columns[0].domain.logSize() + 2))
-            first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _DeviceTranscript(dch, alphas))
+            # the whole layer loop is ONE library call (tstwo_fri_commit_layers); FriCommitPlan captures the per-layer calls of
+            # _commit_layers instead (a capture cannot allocate)
+            if os.environ.get("TSTWO_FRI_COMMIT_HOST_LOOP"):            # A/B timing: round 2's loop, ~10 C-ABI calls per layer
+                first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _DeviceTranscript(dch, alphas))
+            else:
+                first_layer, inner, layer_eval = FriProver._commit_layers_in_library(config, columns, twiddles, dch, alphas)
             dch.sync_to_host()                                               # the host channel continues from the device state
         else:
             first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _HostTranscript(channel))
@@ -320,6 +326,37 @@ class FriProver:
         first_log = (columns[0].domain.size() >> CIRCLE_TO_LINE_FOLD_STEP).bit_length() - 1
         return (all(HipFriOps.can_fold_on_device(c.domain, twiddles) for c in columns)
                 and HipFriOps.can_fold_on_device(LineDomain(Coset.half_odds(first_log)), twiddles))
+
+    @staticmethod
+    def _commit_layers_in_library(config: FriConfig, columns, twiddles: TwiddleTree, dch: DeviceChannel, alphas) -> tuple:
+        """commitInnerLayers (fri.ts:676-716) through tstwo_fri_commit_layers: first-layer tree, then per layer mix root / draw
+        alpha / fold / commit on the device, in one call; the buffers it returns are adopted by the host objects below."""
+        import ctypes as C
+        logs = [c.domain.logSize() for c in columns]
+        first_log = logs[0] - CIRCLE_TO_LINE_FOLD_STEP
+        last_log = config.last_layer_domain_size().bit_length() - 1
+        cap = max(first_log - last_log, 0) + 1
+        outs = (L.FriLayerOut * cap)()
+        n_out, first = C.c_size_t(0), L.vp()
+        L.call("tstwo_fri_commit_layers", L.ptr_array([cc.ptr for c in columns for cc in c.values.columns]), L.u32x(logs), len(columns),
+               C.c_void_p(twiddles.itwiddles.ptr), twiddles.log_size, last_log, C.c_void_p(dch.buf.ptr), C.c_void_p(alphas.ptr),
+               alphas.nbytes // 16, C.byref(first), outs, cap, C.byref(n_out))
+
+        def tree_of(ptr, max_log):
+            buf = L.DeviceBuffer.adopt(ptr, 32 * ((2 << max_log) - 1))
+            return MerkleProver([DeviceHashLayer(buf, 1 << k, 32 * ((1 << k) - 1)) for k in range(max_log + 1)], buf, None)
+
+        def eval_of(o, domain):
+            n = 1 << o.log_size
+            cols = [HipColumn(_buf=L.DeviceBuffer.adopt(o.cols[k], 4 * n), _len=n) for k in range(4)]
+            return LineEvaluation(domain, SecureColumnByCoords(cols))
+        first_layer = FriFirstLayerProver(columns, tree_of(first.value, logs[0]))
+        domain = LineDomain(Coset.half_odds(first_log))
+        inner = []
+        for i in range(n_out.value - 1):
+            inner.append(FriInnerLayerProver(eval_of(outs[i], domain), tree_of(outs[i].layers, outs[i].log_size)))
+            domain = domain.double()
+        return first_layer, inner, eval_of(outs[n_out.value - 1], domain)
 
     @staticmethod
     def _commit_layers(config: FriConfig, columns, twiddles: TwiddleTree, transcript) -> tuple:
