@@ -62,12 +62,16 @@ def _is_light(ins):
     return op in LIGHT and not re.search(r"\bs\d+\b|\bs\[|0x[0-9a-f]{3,}|vcc|exec", args)
 
 
-@pytest.mark.parametrize("tu,pattern,min_phases", [
-    ("cfft", r"k_cfft_bILb0ELi13ELb0E", 40), ("cfft", r"k_cfft_bILb1ELi13ELb0E", 40),
-    ("cfft", r"k_cfft_aILb0ELi9ELi0ELi14E", 30), ("cfft", r"k_cfft_aILb1ELi9ELi0ELi14E", 30),
-    ("merkle", r"k_merkle_leaf_staticILi2E", 300), ("merkle", r"k_merkle_innerE", 150),
+@pytest.mark.parametrize("tu,pattern,min_phases,min_light_share", [
+    ("cfft", r"k_cfft_bILb0ELi13ELb0E", 40, 0.9), ("cfft", r"k_cfft_bILb1ELi13ELb0E", 40, 0.9),
+    ("cfft", r"k_cfft_aILb0ELi9ELi0ELi14E", 30, 0.9), ("cfft", r"k_cfft_aILb1ELi9ELi0ELi14E", 30, 0.9),
+    ("merkle", r"k_merkle_leaf_staticILi2E", 300, 0.9), ("merkle", r"k_merkle_innerE", 150, 0.9),
+    # round 3: the 8-rows-per-lane field kernels on field8.cuh (quotients, QM31 batch inverse through the norms).  Their
+    # priority-0 stretches also hold what cannot be phased — the one Fermat chain per 8 values and the tree products around it
+    # (f8::inverse8), issued in program order at low priority on purpose — hence the lower share of light instructions there.
+    ("quotients", r"k_quotients8ILb1E", 80, 0.7), ("field_ops", r"k_qm31_batch_inverse_normE", 60, 0.7),
 ])
-def test_hot_kernels_are_phased_and_use_global_memory_instructions(tu, pattern, min_phases, tmp_path):
+def test_hot_kernels_are_phased_and_use_global_memory_instructions(tu, pattern, min_phases, min_light_share, tmp_path):
     kernels = _disasm(tu, tmp_path)
     names = [k for k in kernels if re.search(pattern, k)]
     assert len(names) == 1, names
@@ -84,12 +88,12 @@ def test_hot_kernels_are_phased_and_use_global_memory_instructions(tu, pattern, 
     # compression, where the state still holds constants (literal operands)
     n_light = sum(sum(1 for i in p[1] if _is_light(i)) for p in light_runs)
     n_all = sum(len(p[1]) for p in light_runs)
-    assert n_light >= 0.9 * n_all, (n_light, n_all)
+    assert n_light >= min_light_share * n_all, (n_light, n_all)
     # and the heavy runs hold the multiplies / mins / rotates: no long stretch of light instructions at high priority
     for prio, run in heavy_runs:
         longest = cur = 0
         for i in run:
             cur = cur + 1 if _is_light(i) else 0
             longest = max(longest, cur)
-        assert longest <= 12, (names[0], longest)
+        assert longest <= (12 if min_light_share >= 0.9 else 16), (names[0], longest)      # field8 kernels: + operand shuffles (v_mov) behind a run
 

@@ -341,8 +341,13 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), TSTWO_B_WAVES) k_cfft_b(ColPt
 // they are loaded once from the small polynomial, the replicated layers are skipped, and the result goes to `cols`.
 // LOGT (12..14) = log2 of the tile: 2^(LOGT-4) lanes.  14 is the default; the smaller tiles exist for transforms of few
 // columns, where 2^(n-14) tiles would leave most of the 256 CUs without a workgroup.
+#ifdef TSTWO_A_WAVES          // experiments: minimum waves per SIMD asked of the strided pass (8 = two 1024-lane workgroups per CU)
+#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__(1 << (LOGT - 4), TSTWO_A_WAVES)
+#else
+#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__(1 << (LOGT - 4))
+#endif
 template <bool INV, int K, int EXT = 0, int LOGT = 14>
-__global__ void __launch_bounds__(1 << (LOGT - 4)) k_cfft_a(ColPtrs cols, typename SrcTable<EXT>::type src, u32 n_cols, u32 total_items, u32 n,
+__global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EXT>::type src, u32 n_cols, u32 total_items, u32 n,
                                                 u32 lo, const u32 *__restrict__ tw_end, u32 scale) {
     static_assert(EXT == 0 || (!INV && K >= 2 && EXT <= 2), "fused extension: forward pass with two register layers");
     static_assert(LOGT >= 12 && LOGT <= 14 && LOGT - K >= 4, "strided tile: rows of at least 16 words");

@@ -73,9 +73,6 @@ constexpr int kMaxColsPerLaunch = 64;    // CFFT / bit-reverse batch chunk
 // (`ext`), so that a batch of thousands of small columns is still ONE launch instead of one per 64 columns.
 struct ColPtrs { u32 *p[kMaxColsPerLaunch]; u32 *const *ext; };
 #ifdef __HIPCC__
-// The zero-inverse flag lives in host-coherent memory: a plain store of 1 (every writer writes the same value, and only when an
-// input WAS zero — the rare, failing case) is visible to the host once the kernel has completed.
-__device__ __forceinline__ void raise_flag(u32 *flag) { *(volatile u32 *)flag = 1u; }
 // (VALU issue model, phase<PRIO>(values...) and vgpr_P(): phase.cuh, included by m31.cuh)
 // Accesses to COLUMN data go through these: a column pointer comes out of a pointer table, so to the compiler it is a generic
 // address and a plain dereference is a flat_load / flat_store — vector-memory instructions that ALSO count on lgkmcnt, which
@@ -84,6 +81,9 @@ __device__ __forceinline__ void raise_flag(u32 *flag) { *(volatile u32 *)flag = 
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 typedef u32 u32x2_t __attribute__((ext_vector_type(2)));
 #define TSTWO_GLOBAL __attribute__((address_space(1)))
+// The zero-inverse flag lives in host-coherent memory: a plain store of 1 (every writer writes the same value, and only when an
+// input WAS zero — the rare, failing case) is visible to the host once the kernel has completed.
+__device__ __forceinline__ void raise_flag(u32 *flag) { *(volatile TSTWO_GLOBAL u32 *)flag = 1u; }
 __device__ __forceinline__ uint4 gload4(const u32 *p) {
     const u32x4_t v = *(const TSTWO_GLOBAL u32x4_t *)p;
     return make_uint4(v.x, v.y, v.z, v.w);

@@ -4,8 +4,8 @@
 // operation is written opcode by opcode over the 8 instances: runs of 8 (or more) heavy instructions at kPrioHeavy
 // (v_mad_u64_u32, v_alignbit, v_min: port 0 only), runs of light VOP2 at kPrioLight (add / sub / and / shifts on VGPR
 // operands: either port, so they pair with another wave's heavy run).  The modulus lives in a VGPR (a literal operand makes
-// an add heavy).  Every routine ends in a heavy run and LEAVES THE WAVE AT kPrioHeavy; the caller drops to kPrioLight
-// (f8::done) before anything that is not phased.  Canonical in, canonical out, bit-identical to m31.cuh.
+// an add heavy).  Every routine ends in a heavy run and closes it: the wave is back at kPrioLight on return.  Canonical in,
+// canonical out, bit-identical to m31.cuh.
 #pragma once
 #include "m31.cuh"
 
@@ -18,6 +18,15 @@ __device__ __forceinline__ void pin(T (&a)[8]) {
     asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
 }
 __device__ __forceinline__ void done() { phase<kPrioLight>(); }
+// A phase boundary that several arrays cross: each is pinned in front of the s_setprio (its producers stay before it) AND behind
+// it (its consumers stay after it).  A value pinned in front only does not hold its consumers back: a multiply-add run whose
+// operands were all pinned that way was found scheduled ahead of the s_setprio 3 that should have opened it.
+template <int PRIO, class... A>
+__device__ __forceinline__ void boundary(A &...arrs) {
+    (pin(arrs), ...);
+    phase<PRIO>();
+    (pin(arrs), ...);
+}
 
 // r = a * b (products < 2^62): H 8 x mad, 8 x alignbit | L 8 x (and, add, sub) | H 8 x min
 __device__ __forceinline__ void mul(u32 (&r)[8], u32 (&a)[8], u32 (&b)[8]) {
@@ -38,7 +47,7 @@ __device__ __forceinline__ void mul(u32 (&r)[8], u32 (&a)[8], u32 (&b)[8]) {
     phase<kPrioHeavy>(d);
 #pragma unroll
     for (int e = 0; e < 8; e++) r[e] = min(s[e], d[e]);
-    pin(r);          // the closing run stays in front of whatever boundary comes next
+    phase<kPrioLight>(r);          // the closing heavy run ends here: whatever follows (shuffles, the next routine) starts light
 }
 // r = a * b for a wave-uniform / per-lane scalar b
 __device__ __forceinline__ void mul_s(u32 (&r)[8], u32 (&a)[8], u32 b) {
@@ -59,7 +68,7 @@ __device__ __forceinline__ void add(u32 (&r)[8], u32 (&a)[8], u32 (&b)[8]) {
     phase<kPrioHeavy>(d);
 #pragma unroll
     for (int e = 0; e < 8; e++) r[e] = min(s[e], d[e]);
-    pin(r);          // the closing run stays in front of whatever boundary comes next
+    phase<kPrioLight>(r);          // the closing heavy run ends here: whatever follows (shuffles, the next routine) starts light
 }
 __device__ __forceinline__ void sub(u32 (&r)[8], u32 (&a)[8], u32 (&b)[8]) {
     const u32 P = vgpr_P();
@@ -72,7 +81,7 @@ __device__ __forceinline__ void sub(u32 (&r)[8], u32 (&a)[8], u32 (&b)[8]) {
     phase<kPrioHeavy>(d);
 #pragma unroll
     for (int e = 0; e < 8; e++) r[e] = min(s[e], d[e]);
-    pin(r);          // the closing run stays in front of whatever boundary comes next
+    phase<kPrioLight>(r);          // the closing heavy run ends here: whatever follows (shuffles, the next routine) starts light
 }
 // r[e] = bit e of MASK ? a[e] - b[e] : a[e] + b[e] (the rows of a lane differ by signs: conjugate / antipodal domain points)
 template <unsigned MASK>
@@ -90,7 +99,7 @@ __device__ __forceinline__ void addsub(u32 (&r)[8], u32 (&a)[8], u32 (&b)[8]) {
     phase<kPrioHeavy>(d);
 #pragma unroll
     for (int e = 0; e < 8; e++) r[e] = min(s[e], d[e]);
-    pin(r);
+    phase<kPrioLight>(r);
 }
 // r = P - a (a canonical; a = 0 gives P, which is NOT canonical: only for operands of a multiplication, where P acts as 0)
 __device__ __forceinline__ void neg_operand(u32 (&r)[8], const u32 (&a)[8]) {
@@ -136,7 +145,7 @@ __device__ __forceinline__ void reduce(u32 (&r)[8], u64 (&acc)[8]) {
     phase<kPrioHeavy>(d);
 #pragma unroll
     for (int e = 0; e < 8; e++) r[e] = min(s[e], d[e]);
-    pin(r);          // the closing run stays in front of whatever boundary comes next
+    phase<kPrioLight>(r);          // the closing heavy run ends here: whatever follows (shuffles, the next routine) starts light
 }
 // acc (+)= a * b: a heavy run (call between phase<kPrioHeavy> and the reduce)
 __device__ __forceinline__ void mad(u64 (&acc)[8], const u32 (&a)[8], const u32 (&b)[8]) {

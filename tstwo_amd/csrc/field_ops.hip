@@ -226,9 +226,7 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_norm(CSoa4 in, Soa4 
         nb[e] = P - b[e]; nc[e] = P - c[e]; nd2[e] = (P - d[e]) + (P - d[e]);
     }
     u64 re0[8], re1[8], im0[8], im1[8];
-    f8::pin(a); f8::pin(b); f8::pin(c); f8::pin(d);      // every operand of the multiply-add run passes through its boundary
-    f8::pin(dmc2); f8::pin(d2); f8::pin(b2); f8::pin(nb); f8::pin(nc);
-    phase<kPrioHeavy>(nd2);
+    f8::boundary<kPrioHeavy>(a, b, c, d, dmc2, d2, b2, nb, nc, nd2);      // every operand of the multiply-add run crosses its boundary
     f8::mul64(re0, a, a); f8::mad(re0, b, nb); f8::mad(re0, c, dmc2);
     f8::mul64(re1, d, d2);
     f8::mul64(im0, a, b2); f8::mad(im0, c, nd2);
@@ -241,8 +239,7 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_norm(CSoa4 in, Soa4 
     // norms and their inverses
     u64 nn[8];
     u32 n[8], ninv[8];
-    f8::pin(dr);
-    phase<kPrioHeavy>(di);
+    f8::boundary<kPrioHeavy>(dr, di);
     f8::mul64(nn, dr, dr); f8::mad(nn, di, di);
     f8::reduce<false>(n, nn);
     f8::inverse8(ninv, n);
@@ -255,8 +252,7 @@ __global__ void __launch_bounds__(256) k_qm31_batch_inverse_norm(CSoa4 in, Soa4 
     f8::neg_operand(nir, ir);
     f8::neg_operand(nii, ii);
     u64 oa[8], ob[8], oc[8], od[8];
-    f8::pin(a); f8::pin(b); f8::pin(c); f8::pin(d); f8::pin(ir); f8::pin(ii); f8::pin(nir);
-    phase<kPrioHeavy>(nii);
+    f8::boundary<kPrioHeavy>(a, b, c, d, ir, ii, nir, nii);
     f8::mul64(oa, a, ir); f8::mad(oa, b, nii);
     f8::mul64(ob, a, ii); f8::mad(ob, b, ir);
     f8::mul64(oc, c, nir); f8::mad(oc, d, ii);

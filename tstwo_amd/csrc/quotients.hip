@@ -102,8 +102,7 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
             // d^-1 = conj(d) / (re^2 + im^2)
             u64 nn[8];
             u32 n[8], ninv[8], ndb[8];
-            f8::pin(da);
-            phase<kPrioHeavy>(db);
+            f8::boundary<kPrioHeavy>(da, db);
             f8::mul64(nn, da, da); f8::mad(nn, db, db);
             f8::reduce<false>(n, nn);
             f8::inverse8(ninv, n);
@@ -139,8 +138,7 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     u64 a64[8];
-                    f8::pin(fp[0]);
-                    phase<kPrioHeavy>(fp[1]);
+                    f8::boundary<kPrioHeavy>(fp[0], fp[1]);
 #pragma unroll
                     for (int s = 0; s < 8; s++) {           // up to 4 products of < 2^62 plus the 31-bit running value
                         const int k = 2 * h + (s >> 2), r = s & 3;
@@ -179,8 +177,7 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
                     Z[s] = s < 4 ? P - ii[r] : ir[r];
                 }
                 u64 a64[8];
-                f8::pin(U); f8::pin(V); f8::pin(W);
-                phase<kPrioHeavy>(Z);
+                f8::boundary<kPrioHeavy>(U, V, W, Z);
                 f8::mul64(a64, U, V); f8::mad(a64, W, Z);
                 f8::reduce<false>(term[h], a64);
             }
