@@ -9,7 +9,9 @@ Workload = BASELINE.json config 5 as SURVEY.md §8(d) defines it: a FIXED trace 
 (strong scaling): rank g of N owns columns shard_columns(256, N, g) — all 256 at N = 1, 128 / 64 / 32 at N = 2 / 4 / 8 — and
 commits them as 32-column Merkle trees, i.e. 8 trees in all whatever N is: the 8 roots (stwo's TreeVec, one
 CommitmentTreeProver per tree, pcs/prover.ts:62-64,209-237) do not depend on the GPU count.  One step = PolyOps.evaluate
-(Circle FFT) of the rank's columns on CanonicCoset(22).circleDomain() in ONE call, MerkleProver.commit (Blake2s) per tree,
+(Circle FFT) of the rank's columns on CanonicCoset(22).circleDomain() in ONE call, MerkleProver.commit (Blake2s) of the rank's
+trees (one tstwo_merkle_commit_many call — a TreeVec committed together; the trees are byte for byte what tstwo_merkle_commit
+builds one by one, and --commit-per-tree does exactly that),
 then (N > 1) an all-gather of the ranks' 8/N roots of 32 bytes (RCCL, through the C ABI).  `--scaling weak` keeps round 2's
 mode instead (32 columns = one tree per GPU, 32 N columns in all).  Inputs are synthetic (SplitMix64 seeds 100+c) and
 resident in HBM before the timed region; twiddles are prebuilt.  The transform is data-oblivious, so each step re-evaluates
@@ -205,6 +207,7 @@ def main():
     ap.add_argument("--cpu-cols", type=int, default=4, help="columns in the one-thread CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-4 (the `configs` list of the JSON line)")
+    ap.add_argument("--commit-per-tree", action="store_true", help="one tstwo_merkle_commit call per tree instead of one tstwo_merkle_commit_many per step (A/B)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the child rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--pmc-json", default=None, help="tools/pmc_summary.py output of an earlier --pmc run of THIS build, instead of the child passes")
     args = ap.parse_args()
@@ -276,6 +279,11 @@ def main():
     L.call("tstwo_twiddles_build", half_initial, n - 1, C.c_void_p(tw.ptr), C.c_void_p(0))
     layers = [L.DeviceBuffer(32 * ((2 << n) - 1)) for _ in range(n_trees)]
     log_sizes = L.u32x([n] * tree_cols)
+    # the rank's trees as ONE tstwo_merkle_commit_many request table (a TreeVec committed together: equally shaped trees share their
+    # launches, so the latency-bound top of the trees runs side by side); every tree gets exactly what tstwo_merkle_commit writes
+    commit_reqs = (L.CommitRequest * n_trees)()
+    for t in range(n_trees):
+        commit_reqs[t] = L.CommitRequest(tree_ptrs[t], log_sizes, tree_cols, layers[t].ptr)
     # two send/receive slots; the all-gather of step k runs on the library's collective stream and overlaps the CFFT of step k+1
     # (tstwo_comm_wait at the next issue point makes the main stream wait for it on the device, never the host)
     rec = 32 * n_trees                                   # this rank's record: its trees' roots in TreeVec order
@@ -297,8 +305,11 @@ def main():
         L.call("tstwo_cfft_evaluate", col_ptrs, n_cols, n, half_initial, C.c_void_p(tw.ptr), n - 1)
         if ev:
             ev[1].record()
-        for t in range(n_trees):
-            L.call("tstwo_merkle_commit", tree_ptrs[t], log_sizes, tree_cols, C.c_void_p(layers[t].ptr), None)
+        if args.commit_per_tree:
+            for t in range(n_trees):
+                L.call("tstwo_merkle_commit", tree_ptrs[t], log_sizes, tree_cols, C.c_void_p(layers[t].ptr), None)
+        else:
+            L.call("tstwo_merkle_commit_many", commit_reqs, n_trees, None)
         if ev:
             ev[2].record()
         if use_dist:   # the only exchange on the path: 32-byte roots over RCCL/xGMI

@@ -241,6 +241,19 @@ int tstwo_merkle_commit_layer(uint32_t log_size, const uint8_t *prev, const uint
  * may be NULL (then nothing is synchronised).  n_cols == 0 -> one hash of the empty message. */
 int tstwo_merkle_commit(const uint32_t *const *cols, const uint32_t *log_sizes, size_t n_cols,
                         uint8_t *layers, uint8_t root[32]);
+/* Several trees in one launch sequence (a TreeVec committed together, pcs/prover.ts:62-64: the 8 trees of 32 columns that
+ * BASELINE config 5's trace makes on one GPU).  Request r = the arguments of tstwo_merkle_commit for tree r; every tree's layers
+ * buffer receives exactly what tstwo_merkle_commit writes.  When the trees share one shape the static leaf kernel serves (16,
+ * 32, 48 or 64 columns of one log size >= 17; at most 8 trees, 256 columns in all) each launch covers all of them, so that
+ * the latency-bound top of the trees (layers below 2^19 nodes) runs side by side instead of 8 times in a row; any other input
+ * is committed tree by tree.  roots (host, n_trees * 32 bytes) may be NULL (then nothing is synchronised). */
+typedef struct {
+    const uint32_t *const *cols;           /* host array of n_cols device column pointers */
+    const uint32_t *log_sizes;
+    size_t n_cols;
+    uint8_t *layers;                       /* device: tstwo_merkle_layers_bytes(max log) bytes */
+} tstwo_commit_request;
+int tstwo_merkle_commit_many(const tstwo_commit_request *reqs, size_t n_trees, uint8_t *roots);
 size_t tstwo_merkle_layers_bytes(uint32_t max_log);
 /* MerkleProver.decommit (vcs/prover.ts:32-109) on a tree built by tstwo_merkle_commit: `layers` is that call's buffer,
  * `cols` / `col_log_sizes` the same columns in the same order.  Query set k = n_queries[k] ascending positions

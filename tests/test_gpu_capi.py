@@ -829,3 +829,50 @@ def test_host_array_upload_during_graph_capture_is_refused():
     L.call("tstwo_cfft_evaluate", ptrs(evs), len(evs), 13, half_odds(12), vp(tw), 12)
     for i in (0, 1, 69):
         assert (host(evs[i], 1 << 13) == orc.cfft_evaluate(evs_host[i], 13, half_odds(12), otw, 12)).all()
+
+
+@pytest.mark.parametrize("shape", [(4, 32, 17), (8, 32, 18), (3, 16, 19), (2, 64, 17), (5, 48, 17), (2, 32, 12), (1, 32, 17), (3, 20, 17)], ids=str)
+def test_merkle_commit_many_equals_commits_one_by_one(shape):
+    """tstwo_merkle_commit_many: every layer of every tree byte for byte what tstwo_merkle_commit writes for that tree alone —
+    shapes the shared launches serve (16 / 32 / 48 / 64 columns of one log size >= 17, up to 8 trees) and shapes that fall back
+    to the tree-by-tree loop (small trees, other column counts, one tree); one root per tree against the oracle."""
+    n_trees, n_cols, n = shape
+    rng = np.random.default_rng(n_trees * 1000 + n_cols * 10 + n)
+    base = [dev(rng.integers(0, P, size=1 << n, dtype=np.uint32)) for _ in range(min(n_cols + n_trees, 40))]
+    trees = [[base[(t * 7 + k) % len(base)] for k in range(n_cols)] for t in range(n_trees)]       # overlapping column sets: inputs are read only
+    nbytes = 32 * ((2 << n) - 1)
+    many = [dev_empty(nbytes // 4) for _ in range(n_trees)]
+    reqs = (L.CommitRequest * n_trees)()
+    keep = []
+    for t in range(n_trees):
+        cp, lg = ptrs(trees[t]), L.u32x([n] * n_cols)
+        keep += [cp, lg]
+        reqs[t] = L.CommitRequest(cp, lg, n_cols, many[t].ptr)
+    roots = (C.c_uint8 * (32 * n_trees))()
+    L.call("tstwo_merkle_commit_many", reqs, n_trees, roots)
+    single = dev_empty(nbytes // 4)
+    for t in range(n_trees):
+        root = (C.c_uint8 * 32)()
+        L.call("tstwo_merkle_commit", ptrs(trees[t]), L.u32x([n] * n_cols), n_cols, vp(single), root)
+        assert bytes(roots[32 * t:32 * t + 32]) == bytes(root), f"tree {t}"
+        assert (host(many[t], nbytes // 4) == host(single, nbytes // 4)).all(), f"tree {t}: layers differ"
+    cols0 = [host(c, 1 << n) for c in trees[0]]
+    assert bytes(roots[:32]) == orc.mt_merkle_root(cols0, n, 8)
+
+
+def test_merkle_commit_many_mixed_shapes_and_errors():
+    n = 10
+    a = [dev(rand_column(5000 + i, 1 << n)) for i in range(3)]
+    b = [dev(rand_column(5100 + i, 1 << (n - 2))) for i in range(2)]
+    la, lb = dev_empty(8 * ((2 << n) - 1)), dev_empty(8 * ((2 << n) - 1))
+    reqs = (L.CommitRequest * 2)()
+    pa, ga, pb, gb = ptrs(a), L.u32x([n] * 3), ptrs(a + b), L.u32x([n] * 3 + [n - 2] * 2)
+    reqs[0] = L.CommitRequest(pa, ga, 3, la.ptr)
+    reqs[1] = L.CommitRequest(pb, gb, 5, lb.ptr)
+    roots = (C.c_uint8 * 64)()
+    L.call("tstwo_merkle_commit_many", reqs, 2, roots)
+    assert bytes(roots[:32]) == orc.merkle_commit([host(c, 1 << n) for c in a], [n] * 3)[1]
+    assert bytes(roots[32:]) == orc.merkle_commit([host(c, 1 << n) for c in a] + [host(c, 1 << (n - 2)) for c in b], [n] * 3 + [n - 2] * 2)[1]
+    L.call("tstwo_merkle_commit_many", reqs, 0, None)                 # nothing to do
+    with pytest.raises(L.TstwoError, match="null request table"):
+        L.call("tstwo_merkle_commit_many", None, 2, roots)

@@ -74,6 +74,8 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_fri_decompose: { args: [P, u64, P, P], returns: i32 },
   tstwo_merkle_commit_layer: { args: [u32, u64, P, u64, u64], returns: i32 },
   tstwo_merkle_commit: { args: [P, P, u64, u64, P], returns: i32 },
+  // reqs: a packed array of tstwo_commit_request structs (4 x 8 bytes each: cols, log_sizes, n_cols, layers)
+  tstwo_merkle_commit_many: { args: [P, u64, P], returns: i32 },
   tstwo_merkle_layers_bytes: { args: [u32], returns: u64 },
   tstwo_merkle_decommit: { args: [u64, u32, P, P, u64, P, P, P, u64, P, P, P, P, P, P], returns: i32 },
   // reqs: a packed array of tstwo_decommit_request structs (9 x 8 bytes each: layers, max_log (u32, padded), cols, col_log_sizes,

@@ -317,6 +317,23 @@ export class HipMerkleProver {
     check(hip.tstwo_merkle_commit(ptr(ptrs(columns.map((c) => c.dev))), ptr(u32s(logs)), BigInt(columns.length), layers.dev, ptr(root)));
     return new HipMerkleProver(layers, maxLog, root);
   }
+  /** Several trees in one launch sequence (tstwo_merkle_commit_many: a TreeVec committed together, pcs/prover.ts:62-64): the same
+   *  trees as commit() one by one; equally shaped trees (16 / 32 / 48 / 64 columns of one size) share their launches. */
+  static commitMany(columnSets: readonly (readonly HipColumn[])[]): HipMerkleProver[] {
+    const n = columnSets.length;
+    const reqs = new BigUint64Array(4 * n), roots = new Uint8Array(32 * Math.max(n, 1));
+    const keep: unknown[] = [], bufs: DeviceBuffer[] = [], maxLogs: number[] = [];
+    columnSets.forEach((cols, r) => {
+      const logs = cols.map((c) => Math.log2(c.len()));
+      if (!logs.every(Number.isInteger)) throw new Error("length is not power of two");
+      const maxLog = cols.length ? Math.max(...logs) : 0;
+      const layers = new DeviceBuffer(32 * ((2 << maxLog) - 1)), cp = ptrs(cols.map((c) => c.dev)), lg = u32s(logs);
+      keep.push(cp, lg); bufs.push(layers); maxLogs.push(maxLog);
+      reqs[4 * r] = BigInt(ptr(cp)); reqs[4 * r + 1] = BigInt(ptr(lg)); reqs[4 * r + 2] = BigInt(cols.length); reqs[4 * r + 3] = layers.dev;
+    });
+    check(hip.tstwo_merkle_commit_many(ptr(reqs), BigInt(n), ptr(roots)));
+    return bufs.map((b, r) => new HipMerkleProver(b, maxLogs[r]!, roots.slice(32 * r, 32 * r + 32)));
+  }
   root(): Blake2sHash { return new Blake2sHash(this.rootBytes); }
   /** Device address of the root: tstwo_channel_mix_root_draw_felt / tstwo_allgather_roots read it without a host round trip. */
   rootDev(): bigint { return this.layers.dev; }

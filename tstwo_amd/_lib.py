@@ -41,6 +41,11 @@ class FriLayer(C.Structure):
     _fields_ = [("layers", vp), ("max_log", C.c_uint32), ("cols", C.POINTER(vp)), ("eval_logs", u32p), ("n_evals", C.c_size_t)]
 
 
+class CommitRequest(C.Structure):
+    """tstwo_commit_request (include/tstwo_hip.h)."""
+    _fields_ = [("cols", C.POINTER(vp)), ("log_sizes", u32p), ("n_cols", C.c_size_t), ("layers", vp)]
+
+
 class FriLayerOut(C.Structure):
     """tstwo_fri_layer_out (include/tstwo_hip.h)."""
     _fields_ = [("log_size", C.c_uint32), ("cols", vp * 4), ("layers", vp)]
@@ -111,6 +116,7 @@ _SIGS = {
     "tstwo_fri_decompose": [P4, C.c_size_t, P4, u32p],
     "tstwo_merkle_commit_layer": [C.c_uint32, vp, C.POINTER(vp), C.c_size_t, vp],
     "tstwo_merkle_commit": [C.POINTER(vp), u32p, C.c_size_t, vp, u8p],
+    "tstwo_merkle_commit_many": [C.POINTER(CommitRequest), C.c_size_t, u8p],
     "tstwo_grind_blake2s": [u8p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)],
     "tstwo_merkle_decommit": [vp, C.c_uint32, C.POINTER(vp), u32p, C.c_size_t, u32p, C.POINTER(C.POINTER(C.c_uint64)),
                               C.POINTER(C.c_size_t), C.c_size_t, u32p, C.POINTER(C.c_size_t), u8p, C.POINTER(C.c_size_t),

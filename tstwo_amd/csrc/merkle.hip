@@ -184,8 +184,14 @@ __global__ void __launch_bounds__(256) k_merkle_layer(const uint4 *__restrict__ 
 // (1) bottom layer whose column count is exactly 16*NBLK (e.g. the 32-column trace shard): every message word has
 //     a compile-time column index, so the column pointers are fetched once (scalar registers) instead of a
 //     clamp + scalar load + select per word per block.
+// Up to kMaxTrees equally shaped trees per launch (tstwo_merkle_commit_many): blockIdx.y selects the tree — its columns are
+// cols.p[blockIdx.y * 16 * NBLK ...] of the by-value table, its layers buffer ts.t[blockIdx.y].
+constexpr int kMaxTrees = 8;
+struct TreeSet { uint4 *t[kMaxTrees]; };
 template <int NBLK>
-__global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, uint4 *__restrict__ out, size_t n_nodes) {
+__global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, TreeSet outs, size_t n_nodes) {
+    uint4 *__restrict__ out = outs.t[blockIdx.y];
+    const u32 col0 = blockIdx.y * (16 * NBLK);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 rows = (u32)((n_nodes + stride - 1) / stride);
@@ -194,7 +200,7 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, ui
     // word `node` of column k = scalar base (kernel argument) + ONE 32-bit byte offset shared by all columns: global_load with
     // an SGPR base and a VGPR offset, instead of a 64-bit address pair per column in VGPRs (columns are at most 4 GiB: the
     // host takes this kernel for log_size <= 30 only)
-    auto word = [&](int k, u32 byte_off) -> u32 { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)cols.p[k] + byte_off); };
+    auto word = [&](int k, u32 byte_off) -> u32 { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)cols.p[col0 + k] + byte_off); };
     {
         const u32 oc = (u32)min(node0, last_node) * 4u;
 #pragma unroll
@@ -295,7 +301,7 @@ __global__ void __launch_bounds__(256) k_merkle_leaf4(const u32 *__restrict__ c0
 }
 
 // (2) inner layer without columns: node = Blake2s(left || right), one 64-byte block.
-__global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ prev, uint4 *__restrict__ out, size_t n_nodes) {
+__device__ __forceinline__ void merkle_inner_body(const uint4 *__restrict__ prev, uint4 *__restrict__ out, size_t n_nodes) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 rows = (u32)((n_nodes + stride - 1) / stride);
@@ -328,6 +334,15 @@ __global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ 
         out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
         out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
     }
+}
+
+__global__ void __launch_bounds__(256) k_merkle_inner(const uint4 *__restrict__ prev, uint4 *__restrict__ out, size_t n_nodes) {
+    merkle_inner_body(prev, out, n_nodes);
+}
+// the same for layer log_out of every tree of a set (children = its layer log_out + 1)
+__global__ void __launch_bounds__(256) k_merkle_inner_set(TreeSet ts, u32 log_out) {
+    uint4 *layers = ts.t[blockIdx.y];
+    merkle_inner_body(layers + 2 * (((size_t)1 << (log_out + 1)) - 1), layers + 2 * (((size_t)1 << log_out) - 1), (size_t)1 << log_out);
 }
 
 // (3) LEVELS column-free layers in one launch, no exchange at all: a lane owns 2^LEVELS consecutive nodes of layer
@@ -374,7 +389,8 @@ __device__ __forceinline__ Digest subtree_node(uint4 *__restrict__ layers, u32 l
     return d;
 }
 template <int LEVELS>
-__global__ void __launch_bounds__(256) k_merkle_subtree(uint4 *__restrict__ layers, u32 log_child) {
+__global__ void __launch_bounds__(256) k_merkle_subtree(TreeSet ts, u32 log_child) {
+    uint4 *__restrict__ layers = ts.t[blockIdx.y];
     const size_t top = (size_t)blockIdx.x * blockDim.x + threadIdx.x;         // node index in layer log_child - LEVELS
     if (top >= ((size_t)1 << (log_child - LEVELS))) return;
     if constexpr (LEVELS == 2) {
@@ -512,7 +528,8 @@ __device__ __forceinline__ void upq_levels(uint4 *__restrict__ layers, u32 *sh, 
     }
 }
 template <int WG>
-__global__ void __launch_bounds__(WG) k_merkle_upq(uint4 *__restrict__ layers, u32 log_child, u32 levels) {
+__global__ void __launch_bounds__(WG) k_merkle_upq(TreeSet ts, u32 log_child, u32 levels) {
+    uint4 *__restrict__ layers = ts.t[blockIdx.y];
     constexpr u32 Q = WG / 4;
     __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];      // 2Q child digests x 8 words
     const u32 t = threadIdx.x;
@@ -550,14 +567,16 @@ __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__
 }
 
 // Column-free levels log_child-1 .. log_stop of the tree, a few fused launches instead of one launch per level.
-int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
+int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop);
+int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_stop) {
     Context &c = ctx();
+    uint8_t *layers = (uint8_t *)ts.t[0];             // (the one-lane scheme kept for A/B timing handles one tree)
     static const bool one_lane = getenv("TSTWO_MERKLE_UP_ONELANE") != nullptr;     // previous scheme, kept for A/B timing
     static const bool small_wg = getenv("TSTWO_MERKLE_UP_SMALLWG") != nullptr;     // 256-lane workgroups only (A/B timing)
     while (log_child > log_stop) {
         const u32 remaining = log_child - log_stop;
         const u32 parents_log = log_child - 1;
-        if (one_lane) {
+        if (one_lane && n_trees == 1) {
             if (parents_log >= 8) {               // >= 256 parents: 256-lane workgroups, up to 5 levels each
                 u32 levels = remaining < 5 ? remaining : 5;
                 hipLaunchKernelGGL(k_merkle_up<256>, dim3(1u << (parents_log - 8)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
@@ -567,19 +586,24 @@ int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
                 log_child -= remaining;
             }
         } else if (parents_log <= 8 && !small_wg) {   // <= 256 parents: ONE workgroup of 256 quads finishes the tree (up to 9 levels)
-            hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1), dim3(1024), 0, c.stream, (uint4 *)layers, log_child, remaining);
+            hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1, n_trees), dim3(1024), 0, c.stream, ts, log_child, remaining);
             log_child -= remaining;
         } else if (parents_log >= 6) {            // >= 64 parents: 64 quads per workgroup, 64 -> 1 = up to 7 levels each
             u32 levels = remaining < 7 ? remaining : 7;
-            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1u << (parents_log - 6)), dim3(256), 0, c.stream, (uint4 *)layers, log_child, levels);
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1u << (parents_log - 6), n_trees), dim3(256), 0, c.stream, ts, log_child, levels);
             log_child -= levels;
         } else {
-            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1, n_trees), dim3(256), 0, c.stream, ts, log_child, remaining);
             log_child -= remaining;
         }
     }
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
+}
+int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
+    TreeSet one = {};
+    one.t[0] = (uint4 *)layers;
+    return commit_upper_levels(one, 1, log_child, log_stop);
 }
 
 // ---- Blake2sChannel on the device (channel/blake2.ts:25-224, Rust semantics).  State = 10 words: digest[8], n_challenges,
@@ -686,11 +710,13 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
     if (!prev && log_size <= 30 && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !getenv("TSTWO_MERKLE_GENERIC")) {
         HashColPtrs hp;
         for (size_t k = 0; k < n_cols; k++) hp.p[k] = cols[k];
+        TreeSet one = {};
+        one.t[0] = (uint4 *)out;
         switch (n_cols / 16) {
-            case 1: hipLaunchKernelGGL(k_merkle_leaf_static<1>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
-            case 2: hipLaunchKernelGGL(k_merkle_leaf_static<2>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
-            case 3: hipLaunchKernelGGL(k_merkle_leaf_static<3>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
-            default: hipLaunchKernelGGL(k_merkle_leaf_static<4>, dim3(blocks), dim3(256), 0, c.stream, hp, (uint4 *)out, n_nodes); break;
+            case 1: hipLaunchKernelGGL(k_merkle_leaf_static<1>, dim3(blocks), dim3(256), 0, c.stream, hp, one, n_nodes); break;
+            case 2: hipLaunchKernelGGL(k_merkle_leaf_static<2>, dim3(blocks), dim3(256), 0, c.stream, hp, one, n_nodes); break;
+            case 3: hipLaunchKernelGGL(k_merkle_leaf_static<3>, dim3(blocks), dim3(256), 0, c.stream, hp, one, n_nodes); break;
+            default: hipLaunchKernelGGL(k_merkle_leaf_static<4>, dim3(blocks), dim3(256), 0, c.stream, hp, one, n_nodes); break;
         }
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
@@ -1110,10 +1136,12 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
                 const size_t tops = (size_t)1 << (lg - run + 1);
                 const unsigned blocks = ceil_div(tops, 256);
                 Context &c = ctx();
+                TreeSet one = {};
+                one.t[0] = (uint4 *)layers;
                 switch (run) {
-                    case 2: hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(blocks), dim3(256), 0, c.stream, (uint4 *)layers, (u32)lg + 1); break;
-                    case 3: hipLaunchKernelGGL(k_merkle_subtree<3>, dim3(blocks), dim3(256), 0, c.stream, (uint4 *)layers, (u32)lg + 1); break;
-                    default: hipLaunchKernelGGL(k_merkle_subtree<4>, dim3(blocks), dim3(256), 0, c.stream, (uint4 *)layers, (u32)lg + 1); break;
+                    case 2: hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1); break;
+                    case 3: hipLaunchKernelGGL(k_merkle_subtree<3>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1); break;
+                    default: hipLaunchKernelGGL(k_merkle_subtree<4>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1); break;
                 }
                 if (hipGetLastError() != hipSuccess) rc = set_error(TSTWO_ERR_HIP, "merkle: subtree kernel launch failed");
                 lg -= run;
@@ -1130,6 +1158,85 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
     if (root) {
         int rc2 = small_d2h(root, layers, 32);
         if (rc2) return rc2;
+    }
+    return TSTWO_OK;
+}
+
+
+// Several trees in ONE launch sequence (a TreeVec committed together: the 8 trees of BASELINE config 5's trace on one GPU,
+// pcs/prover.ts:62-64).  A tree ends in ~65 us of launches with almost nothing to do (the layers below 2^19 nodes: 1 M of a
+// 32-column log-22 tree's 12.6 M compressions); committed one after the other, 8 trees pay that 8 times.  When the trees
+// have ONE shape that the static leaf kernel serves (16 / 32 / 48 / 64 columns of one log size, at most 8 trees and 256
+// columns in all), every launch covers all trees (blockIdx.y = tree) and the tails run side by side; any other input is
+// committed tree by tree.  Bit-identical to tstwo_merkle_commit per tree (same kernels, same nodes).
+int tstwo_merkle_commit_many(const tstwo_commit_request *reqs, size_t n_trees, uint8_t *roots) {
+    TSTWO_REQUIRE_READY();
+    if (n_trees && !reqs) return set_error(TSTWO_ERR_BAD_ARG, "merkle: null request table");
+    bool uniform = n_trees >= 2 && n_trees <= (size_t)kMaxTrees && !getenv("TSTWO_MERKLE_GENERIC") && !getenv("TSTWO_MERKLE_NO_BATCH");
+    static const int up_log = getenv("TSTWO_MERKLE_UP_LOG") ? atoi(getenv("TSTWO_MERKLE_UP_LOG")) : 16;
+    size_t n_cols = n_trees ? reqs[0].n_cols : 0;
+    u32 lg = 0;
+    for (size_t r = 0; r < n_trees && uniform; r++) {
+        const tstwo_commit_request &q = reqs[r];
+        if (!q.layers || !q.cols || !q.log_sizes) return set_error(TSTWO_ERR_BAD_ARG, "merkle: null argument");
+        uniform = q.n_cols == n_cols && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && n_cols * n_trees <= (size_t)kMaxHashCols &&
+                  (((uintptr_t)q.layers) & 15) == 0;
+        for (size_t k = 0; k < q.n_cols && uniform; k++) {
+            if (!q.cols[k]) return set_error(TSTWO_ERR_BAD_ARG, "null device pointer in table");
+            if (r == 0 && k == 0) lg = q.log_sizes[0];
+            uniform = q.log_sizes[k] == lg;
+        }
+    }
+    uniform = uniform && lg >= (u32)up_log + 1 && lg <= 30;
+    if (!uniform) {
+        for (size_t r = 0; r < n_trees; r++) {
+            int rc = tstwo_merkle_commit(reqs[r].cols, reqs[r].log_sizes, reqs[r].n_cols, reqs[r].layers, nullptr);
+            if (rc) return rc;
+        }
+    } else {
+        Context &c = ctx();
+        HashColPtrs hp;
+        TreeSet leaf = {}, ts = {};
+        for (size_t r = 0; r < n_trees; r++) {
+            for (size_t k = 0; k < n_cols; k++) hp.p[r * n_cols + k] = reqs[r].cols[k];
+            ts.t[r] = (uint4 *)reqs[r].layers;
+            leaf.t[r] = (uint4 *)(reqs[r].layers + 32 * (((size_t)1 << lg) - 1));
+        }
+        const size_t n_nodes = (size_t)1 << lg;
+        unsigned blocks = ceil_div(n_nodes, 256);
+        static const unsigned cap_mult = getenv("TSTWO_MERKLE_CAP") ? (unsigned)atoi(getenv("TSTWO_MERKLE_CAP")) : 32u;
+        const unsigned cap = (unsigned)c.n_cus * cap_mult / (unsigned)n_trees;          // the same lanes in flight as one tree's launch
+        if (blocks > cap) blocks = cap ? cap : 1;
+        const dim3 grid(blocks, (unsigned)n_trees);
+        switch (n_cols / 16) {
+            case 1: hipLaunchKernelGGL(k_merkle_leaf_static<1>, grid, dim3(256), 0, c.stream, hp, leaf, n_nodes); break;
+            case 2: hipLaunchKernelGGL(k_merkle_leaf_static<2>, grid, dim3(256), 0, c.stream, hp, leaf, n_nodes); break;
+            case 3: hipLaunchKernelGGL(k_merkle_leaf_static<3>, grid, dim3(256), 0, c.stream, hp, leaf, n_nodes); break;
+            default: hipLaunchKernelGGL(k_merkle_leaf_static<4>, grid, dim3(256), 0, c.stream, hp, leaf, n_nodes); break;
+        }
+        // column-free layers lg-1 .. up_log two per launch (in-lane subtrees), a single leftover layer on its own, then the
+        // quad-lane levels: the launch sequence of tstwo_merkle_commit for a tree whose columns all sit on the leaf layer
+        int cur = (int)lg - 1;
+        while (cur - 1 >= up_log) {
+            hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(ceil_div((size_t)1 << (cur - 1), 256), (unsigned)n_trees), dim3(256), 0, c.stream, ts, (u32)cur + 1);
+            cur -= 2;
+        }
+        if (cur >= up_log) {
+            unsigned b1 = ceil_div((size_t)1 << cur, 256);
+            if (b1 > cap) b1 = cap ? cap : 1;
+            hipLaunchKernelGGL(k_merkle_inner_set, dim3(b1, (unsigned)n_trees), dim3(256), 0, c.stream, ts, (u32)cur);
+            cur -= 1;
+        }
+        TSTWO_LAUNCH_CHECK();
+        int rc = commit_upper_levels(ts, (unsigned)n_trees, (u32)cur + 1, 0);
+        if (rc) return rc;
+    }
+    if (roots) {
+        std::vector<GatherItem> items(n_trees);
+        for (size_t r = 0; r < n_trees; r++) items[r] = {(const u32 *)reqs[r].layers, 0};
+        DecommitLists l;
+        l.hashes = items;
+        return run_decommit(l, nullptr, roots, nullptr);
     }
     return TSTWO_OK;
 }

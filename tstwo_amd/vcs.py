@@ -71,6 +71,35 @@ class MerkleProver:
         layers = [DeviceHashLayer(buf, 1 << k, 32 * ((1 << k) - 1)) for k in range(max_log + 1)]
         return MerkleProver(layers, buf, bytes(root) if sync_root else None)
 
+    @staticmethod
+    def commit_many(column_sets, sync_root: bool = True) -> list:
+        """MerkleProver.commit of several trees in one launch sequence (tstwo_merkle_commit_many: a TreeVec committed together,
+        pcs/prover.ts:62-64).  Same trees as commit() one by one; equally shaped trees share their launches."""
+        column_sets = [list(cs) for cs in column_sets]
+        reqs = (L.CommitRequest * max(len(column_sets), 1))()
+        keep, bufs, max_logs = [], [], []
+        for r, cols in enumerate(column_sets):
+            logs = []
+            for c in cols:
+                n = c.len()
+                if n == 0 or n & (n - 1):
+                    raise ValueError("column length is not a power of two")
+                logs.append(n.bit_length() - 1)
+            max_log = max(logs) if cols else 0
+            buf = L.DeviceBuffer(32 * ((2 << max_log) - 1))
+            colp, lg = L.ptr_array([c.ptr for c in cols]), L.u32x(logs)
+            keep += [colp, lg]
+            reqs[r] = L.CommitRequest(colp, lg, len(cols), buf.ptr)
+            bufs.append(buf)
+            max_logs.append(max_log)
+        roots = (C.c_uint8 * (32 * max(len(column_sets), 1)))() if sync_root else None
+        L.call("tstwo_merkle_commit_many", reqs, len(column_sets), roots)
+        out = []
+        for r, (buf, max_log) in enumerate(zip(bufs, max_logs)):
+            layers = [DeviceHashLayer(buf, 1 << k, 32 * ((1 << k) - 1)) for k in range(max_log + 1)]
+            out.append(MerkleProver(layers, buf, bytes(roots[32 * r:32 * r + 32]) if sync_root else None))
+        return out
+
     def root(self) -> bytes:
         if self._root is None:                      # committed asynchronously (sync_root=False): fetch the 32 bytes now
             self._root = self._buf.download(np.uint8, 32).tobytes()
