@@ -74,6 +74,19 @@ def test_config5_trace_on_one_gpu_every_word_and_8_roots(trace):
     for i, (b, e) in enumerate(zip(bufs, evals)):
         got = b.download(np.uint32, 1 << N_LOG)
         assert (got == e).all(), f"evaluation column {i}: {int((got != e).sum())} words differ, first at {int(np.argmax(got != e))}"
+    # the same 8 trees committed together (tstwo_merkle_commit_many: what bench.py's step calls)
+    many = [L.DeviceBuffer(32 * ((2 << N_LOG) - 1)) for _ in range(TOTAL // TREE)]
+    reqs = (L.CommitRequest * len(many))()
+    keep = []
+    for t in range(len(many)):
+        cp, lg = L.ptr_array([b.ptr for b in bufs[t * TREE:(t + 1) * TREE]]), L.u32x([N_LOG] * TREE)
+        keep += [cp, lg]
+        reqs[t] = L.CommitRequest(cp, lg, TREE, many[t].ptr)
+    roots_many = (C.c_uint8 * (32 * len(many)))()
+    L.call("tstwo_merkle_commit_many", reqs, len(many), roots_many)
+    assert [bytes(roots_many[32 * t:32 * t + 32]) for t in range(len(many))] == roots
+    for m in many:
+        m.free()
     # one tree over all 256 columns (leaf = 1 KiB): the shape a one-tree-per-GPU split would give at N = 1
     layers = L.DeviceBuffer(32 * ((2 << N_LOG) - 1))
     root = (C.c_uint8 * 32)()
