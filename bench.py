@@ -238,7 +238,13 @@ def main():
     dev_index = local_rank % max(n_dev, 1)
     collective = os.environ.get("TSTWO_BENCH_COLLECTIVE", "rccl")
     use_dist = world > 1 or bool(os.environ.get("TSTWO_FORCE_DIST"))   # FORCE: rehearse the collective path at world size 1
+    saved_stdout = None
     if use_dist:
+        # gloo announces its connections on the C-level stdout ("[Gloo] Rank 0 is connected to ..."): route fd 1 to stderr until the
+        # JSON line is printed, so that stdout carries that ONE line and nothing else
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
@@ -469,7 +475,12 @@ def main():
             from bench_configs import run_configs
             del dev_cols[:], layers[:]
             out["configs"] = run_configs(reps=10, no_cpu=args.no_cpu)      # BASELINE configs 1-4, same JSON line
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)
         if root_ok is False:
             raise SystemExit("bench.py: the GPU Merkle roots of the step differ from the CPU oracle's: the measured numbers are void")
 
