@@ -432,18 +432,26 @@ class FriProver:
             total_evals += len(evs)
         nq = len(queries.positions)
         qarr = (C.c_uint64 * max(nq, 1))(*queries.positions)
-        # capacities: a query touches one coset of 2^step positions per evaluation and layer; <= 2 hashes per level and position
+        # capacities: a query touches one coset of 2^step positions per evaluation and layer; a position asks for at most one sibling
+        # hash per level.  Should an estimate fall short the library reports the exact sizes and the call is repeated with them.
         cap_e = max(1, 2 * nq * total_evals)
-        cap_h = max(1, sum(4 * nq * (len(l.merkle_tree.layers)) for l in layers))
+        cap_h = max(1, sum(2 * nq * (len(l.columns) if r == 0 else 1) * len(l.merkle_tree.layers) for r, l in enumerate(layers)))
         cap_w = max(1, 8 * nq * total_evals)
-        evals = np.empty(4 * cap_e, dtype=np.uint32)
-        hashes = np.empty(32 * cap_h, dtype=np.uint8)
-        colwit = np.empty(cap_w, dtype=np.uint32)
         roots = np.empty(32 * n, dtype=np.uint8)
         counts = (C.c_size_t * (3 * n))()
-        totals = (C.c_size_t * 3)(cap_e, cap_h, cap_w)
-        L.call("tstwo_fri_decommit", descs, n, qarr, nq, max_log, CIRCLE_TO_LINE_FOLD_STEP, FOLD_STEP, evals.ctypes.data_as(L.u32p),
-               hashes.ctypes.data_as(L.u8p), colwit.ctypes.data_as(L.u32p), roots.ctypes.data_as(L.u8p), counts, totals)
+        for attempt in range(2):
+            evals = np.empty(4 * cap_e, dtype=np.uint32)
+            hashes = np.empty(32 * cap_h, dtype=np.uint8)
+            colwit = np.empty(cap_w, dtype=np.uint32)
+            totals = (C.c_size_t * 3)(cap_e, cap_h, cap_w)
+            try:
+                L.call("tstwo_fri_decommit", descs, n, qarr, nq, max_log, CIRCLE_TO_LINE_FOLD_STEP, FOLD_STEP, evals.ctypes.data_as(L.u32p),
+                       hashes.ctypes.data_as(L.u8p), colwit.ctypes.data_as(L.u32p), roots.ctypes.data_as(L.u8p), counts, totals)
+                break
+            except L.TstwoError as e:
+                if attempt or "output buffer too small" not in str(e):
+                    raise
+                cap_e, cap_h, cap_w = max(1, totals[0]), max(1, totals[1]), max(1, totals[2])
         hb, rb = hashes.tobytes(), roots.tobytes()
         ev = evals[:4 * totals[0]].reshape(-1, 4).tolist()
         wl = colwit[:totals[2]].tolist()
