@@ -145,6 +145,11 @@ __device__ __forceinline__ u32 *colp_u(const ColPtrs &c, u32 i) {
 }
 constexpr int kSecondTableOff = (int)sizeof(ColPtrs);     // kernel signature (ColPtrs cols, <ColPtrs | NoSrc> src, ...)
 #endif
+// merkle.hip: tstwo_merkle_commit + the channel's mix_root / draw_felt on its root, as one launch sequence without a separate
+// channel launch where the tree's last launch can carry it
+int merkle_commit_then_channel(const u32 *const *cols, const u32 *log_sizes, size_t n_cols, uint8_t *layers, u32 *chan, u32 *felt);
+// merkle.hip: the FRI commit's last layers (2^log0 <= 2^9 rows and below) in one single-workgroup launch
+int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas);
 // Host: describe columns [0, n_cols) of `cols` in `out`; slot 0/1 = which of the two device tables to use when a launch needs two.
 int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot);
 constexpr int kMaxHashCols = 256;        // Merkle: columns absorbed per launch (multiple of 16)

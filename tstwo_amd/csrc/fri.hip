@@ -42,10 +42,12 @@ __global__ void __launch_bounds__(256) k_fold_line(CSoa4 in, Soa4 out, size_t n_
 
 // fri.ts:162-192.  Twiddle = circle-layer inverse twiddle: either explicit inv_y[i], or derived from the
 // layer-1 slice of the inverse tree: +-seg1[(i>>1)^1], negative iff (i ^ (i>>1)) & 1.
-template <bool FROM_TREE>
+// ACCUM = false: dst is written, not updated (dst = alpha f1 + f0) — the first fold of a FRI commit, whose line evaluation starts
+// at zero (fri.ts:687-693): no zero fill of dst, no read of it.
+template <bool FROM_TREE, bool ACCUM = true>
 __global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t n_out, const u32 *__restrict__ twp,
                                                     qm31 alpha, qm31 alpha_sq, const qm31 *__restrict__ alpha_dev) {
-    if (alpha_dev) { alpha = *alpha_dev; alpha_sq = qm31_mul(alpha, alpha); }
+    if (alpha_dev) { alpha = *alpha_dev; if (ACCUM) alpha_sq = qm31_mul(alpha, alpha); }
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += stride) {
         u32 t;
@@ -58,8 +60,11 @@ __global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t
         qm31 f0;
         qm31 f1 = load_pair_fold(src, i, t, &f0);
         qm31 fp = qm31_add(qm31_mul(alpha, f1), f0);
-        qm31 cur = {dst.p[0][i], dst.p[1][i], dst.p[2][i], dst.p[3][i]};
-        qm31 r = qm31_add(qm31_mul(cur, alpha_sq), fp);
+        qm31 r = fp;
+        if (ACCUM) {
+            qm31 cur = {dst.p[0][i], dst.p[1][i], dst.p[2][i], dst.p[3][i]};
+            r = qm31_add(qm31_mul(cur, alpha_sq), fp);
+        }
         dst.p[0][i] = r.a; dst.p[1][i] = r.b; dst.p[2][i] = r.c; dst.p[3][i] = r.d;
     }
 }
@@ -436,26 +441,57 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
         for (size_t i = 0; i < n_columns; i++) for (int k = 0; k < 4; k++) logs[4 * i + k] = col_logs[i];
         void *t = nullptr;
         if ((rc = alloc(&t, tstwo_merkle_layers_bytes(col_logs[0])))) return fail(rc);
-        if ((rc = tstwo_merkle_commit(circle_cols, logs.data(), 4 * n_columns, (uint8_t *)t, nullptr))) return fail(rc);
+        if ((rc = merkle_commit_then_channel(circle_cols, logs.data(), 4 * n_columns, (uint8_t *)t, chan, alphas))) return fail(rc);
         *first_tree = (uint8_t *)t;
     }
     u32 *alpha = alphas;
-    if ((rc = tstwo_channel_mix_root_draw_felt(chan, *first_tree, alpha))) return fail(rc);
     u32 *cur[4];
     u32 cur_log = first_log;
     if ((rc = alloc_eval(cur, cur_log))) return fail(rc);
-    for (int k = 0; k < 4; k++)
-        if ((rc = tstwo_zero(cur[k], sizeof(u32) << cur_log))) return fail(rc);
     size_t nxt = 0;
+    {   // the first fold lands in a line evaluation that starts at zero (fri.ts:687-693): written, not accumulated — bit-identical
+        // to zero-filling it and folding into it (0 * alpha^2 + x = x), without the fill and the read of the zeros
+        if (tw_log > 31 || col_logs[0] - 1 > tw_log) return fail(set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!"));
+        const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (col_logs[0] - 1));
+        Soa4 d4 = {{cur[0], cur[1], cur[2], cur[3]}};
+        CSoa4 s4 = {{circle_cols[0], circle_cols[1], circle_cols[2], circle_cols[3]}};
+        hipLaunchKernelGGL((k_fold_circle<true, false>), dim3(capped_blocks((size_t)1 << cur_log, 256)), dim3(256), 0, ctx().stream, d4, s4,
+                           (size_t)1 << cur_log, seg1, qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha);
+        if (hipGetLastError() != hipSuccess) return fail(set_error(TSTWO_ERR_HIP, "fri commit: fold launch failed"));
+        nxt = 1;
+    }
     auto fold_circle_in = [&]() {      // the circle column whose folded size is the current line layer joins it (same alpha)
         const u32 *const src[4] = {circle_cols[4 * nxt], circle_cols[4 * nxt + 1], circle_cols[4 * nxt + 2], circle_cols[4 * nxt + 3]};
         int r = tstwo_fri_fold_circle_into_line_dev(cur, (size_t)1 << cur_log, src, col_logs[nxt], itw, tw_log, alpha);
         nxt++;
         return r;
     };
-    if ((rc = fold_circle_in())) return fail(rc);
     size_t n = 0;
+    static const bool no_tail = getenv("TSTWO_FRI_NO_TAIL") != nullptr;      // A/B timing: per-layer launches down to the last layer
     while (cur_log > log_last_layer_size) {
+        if (!no_tail && cur_log <= 9 && nxt == n_columns) {
+            // every remaining layer fits one workgroup's LDS: ONE launch does tree / mix / draw / fold for all of them (k_fri_tail)
+            const u32 nl = cur_log - log_last_layer_size;
+            u32 *ev[11][4];
+            uint8_t *trees[10];
+            for (int k = 0; k < 4; k++) ev[0][k] = cur[k];
+            for (u32 i = 0; i < nl; i++) {
+                void *t = nullptr;
+                if ((rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log - i)))) return fail(rc);
+                trees[i] = (uint8_t *)t;
+                if ((rc = alloc_eval(ev[i + 1], cur_log - i - 1))) return fail(rc);
+            }
+            if ((rc = launch_fri_tail(ev, trees, nl, cur_log, itw, tw_log, chan, alphas + 4 * (n + 1)))) return fail(rc);
+            for (u32 i = 0; i < nl; i++) {
+                out[n].log_size = cur_log - i;
+                for (int k = 0; k < 4; k++) out[n].cols[k] = ev[i][k];
+                out[n].layers = trees[i];
+                n++;
+            }
+            for (int k = 0; k < 4; k++) cur[k] = ev[nl][k];
+            cur_log = log_last_layer_size;
+            break;
+        }
         tstwo_fri_layer_out &o = out[n];
         o.log_size = cur_log;
         for (int k = 0; k < 4; k++) o.cols[k] = cur[k];
@@ -463,9 +499,8 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
         if ((rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log)))) return fail(rc);
         o.layers = (uint8_t *)t;
         const u32 lg4[4] = {cur_log, cur_log, cur_log, cur_log};
-        if ((rc = tstwo_merkle_commit(cur, lg4, 4, o.layers, nullptr))) return fail(rc);      // FriInnerLayerProver::new
         alpha = alphas + 4 * (n + 1);
-        if ((rc = tstwo_channel_mix_root_draw_felt(chan, o.layers, alpha))) return fail(rc);
+        if ((rc = merkle_commit_then_channel(cur, lg4, 4, o.layers, chan, alpha))) return fail(rc);      // FriInnerLayerProver::new + mix / draw
         u32 *folded[4];
         if ((rc = alloc_eval(folded, cur_log - 1))) return fail(rc);
         if ((rc = tstwo_fri_fold_line_dev(cur, cur_log, itw, tw_log, alpha, folded))) return fail(rc);

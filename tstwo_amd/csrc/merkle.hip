@@ -497,6 +497,53 @@ __device__ __forceinline__ void b2s_quad_block64(const u32 (&m)[16], u32 j, u32 
     o_hi = h_hi ^ b ^ d;
 }
 
+// ---- Blake2sChannel on the device (channel/blake2.ts:25-224, Rust semantics).  State = 10 words: digest[8], n_challenges,
+// n_sent.  One quad of lanes runs the (latency-bound) compressions; used by the FRI commit loop so that a layer's root
+// never has to travel to the host before the next fold can be launched.
+__device__ __forceinline__ void chan_hash64(const u32 (&m)[16], u32 j, u32 (&digest)[8]) {
+    u32 lo, hi;
+    b2s_quad_block64(m, j, lo, hi);
+    // every lane of the quad needs the whole digest: word k lives in lane k & 3 (lo for k < 4, hi for k >= 4)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        digest[k] = (u32)__builtin_amdgcn_readlane((int)lo, k);
+        digest[4 + k] = (u32)__builtin_amdgcn_readlane((int)hi, k);
+    }
+}
+// mix_root (vcs/blake2_merkle.ts:28-31): digest <- H(digest || root), n_challenges += 1, n_sent <- 0; then (optionally)
+// draw_felt (blake2.ts:158-184): H(digest || LE32(n_sent) || 0^28) until all 8 words < 2P; felt = first 4 words reduced.
+// state in registers of every lane of a wave (d, n_chal, n_sent); root: 8 words (global or LDS); felt: the drawn QM31 (valid in
+// every lane).  Executed by one whole wave (chan_hash64 broadcasts through readlane of lanes 0..3).
+__device__ __forceinline__ void chan_mix_draw(u32 (&d)[8], u32 &n_chal, u32 &n_sent, const u32 *root, bool do_mix, bool do_draw, u32 (&felt)[4]) {
+    const u32 j = threadIdx.x & 3;
+    if (do_mix) {
+        u32 m[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { m[k] = d[k]; m[8 + k] = root[k]; }
+        chan_hash64(m, j, d);
+        n_chal += 1;
+        n_sent = 0;
+    }
+    if (do_draw) {
+        u32 w[8];
+        bool ok = false;
+        // retry probability per round ~ 2^-28; the loop is bounded so that the kernel always terminates (64 rejections in a
+        // row have probability 2^-1792)
+        for (int tries = 0; tries < 64 && !ok; tries++) {
+            u32 m[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { m[k] = d[k]; m[8 + k] = 0; }
+            m[8] = n_sent;
+            n_sent += 1;
+            chan_hash64(m, j, w);
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < 8; k++) ok = ok && (w[k] < 2u * M31_P);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) felt[k] = w[k] >= M31_P ? w[k] - M31_P : w[k];       // M31.reduce of a value < 2P
+    }
+}
 // Levels log_child-1 .. log_child-levels, 4 lanes per node: a workgroup of WG lanes owns WG/4 consecutive parents of the
 // first level and everything above them (WG/4 -> 1 is log2(WG/4)+1 levels).  Children digests live in LDS between levels.
 // the level loop shared by k_merkle_upq and k_merkle_leaf4_upq: `sh` holds the 2*active child digests of this workgroup
@@ -527,8 +574,26 @@ __device__ __forceinline__ void upq_levels(uint4 *__restrict__ layers, u32 *sh, 
         active >>= 1;
     }
 }
+// The launch that produces a tree's root can run the channel's mix_root + draw_felt on it right away (wave 0, root still in LDS):
+// the FRI commit loop's "tree, then channel" pair as one launch (ChanHook; null pointers: no channel step).
+struct ChanHook { u32 *chan, *felt; };
+__device__ __forceinline__ void chan_step_from_lds(const ChanHook &hk, const u32 *root_lds) {
+    if (!hk.chan || threadIdx.x >= 64) return;
+    u32 d[8], f[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = hk.chan[k];
+    u32 n_chal = hk.chan[8], n_sent = hk.chan[9];
+    chan_mix_draw(d, n_chal, n_sent, root_lds, true, hk.felt != nullptr, f);
+    if (hk.felt && threadIdx.x < 4) hk.felt[threadIdx.x] = threadIdx.x == 0 ? f[0] : threadIdx.x == 1 ? f[1] : threadIdx.x == 2 ? f[2] : f[3];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) hk.chan[k] = d[k];
+        hk.chan[8] = n_chal;
+        hk.chan[9] = n_sent;
+    }
+}
 template <int WG>
-__global__ void __launch_bounds__(WG) k_merkle_upq(TreeSet ts, u32 log_child, u32 levels) {
+__global__ void __launch_bounds__(WG) k_merkle_upq(TreeSet ts, u32 log_child, u32 levels, ChanHook hk) {
     uint4 *__restrict__ layers = ts.t[blockIdx.y];
     constexpr u32 Q = WG / 4;
     __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];      // 2Q child digests x 8 words
@@ -540,13 +605,14 @@ __global__ void __launch_bounds__(WG) k_merkle_upq(TreeSet ts, u32 log_child, u3
     }
     __syncthreads();
     upq_levels<WG>(layers, sh, log_child, levels, active);
+    if (log_child == levels) chan_step_from_lds(hk, sh);          // this launch reached layer 0: the root is sh[0..7]
 }
 // A small 4-column tree (every FRI layer below 2^17 rows) without a launch of its own for the leaves: the first 2*active lanes
 // of the workgroup hash one leaf each (16-byte message, vcs/blake2_merkle.ts:9-24), write it to the leaf layer and to LDS,
 // and the quad levels follow in the same launch.
 template <int WG>
 __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__ c0, const u32 *__restrict__ c1, const u32 *__restrict__ c2,
-                                                        const u32 *__restrict__ c3, uint4 *__restrict__ layers, u32 log_leaf, u32 levels) {
+                                                        const u32 *__restrict__ c3, uint4 *__restrict__ layers, u32 log_leaf, u32 levels, ChanHook hk) {
     constexpr u32 Q = WG / 4;
     __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];
     const u32 t = threadIdx.x;
@@ -564,12 +630,24 @@ __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__
     }
     __syncthreads();
     upq_levels<WG>(layers, sh, log_leaf, levels, active);
+    if (log_leaf == levels) chan_step_from_lds(hk, sh);
 }
 
 // Column-free levels log_child-1 .. log_stop of the tree, a few fused launches instead of one launch per level.
+// Set by the FRI commit loop around a tstwo_merkle_commit call: the single-workgroup launch that produces the root takes the
+// channel step with it and clears the hook; a hook still set afterwards means the tree went another way (the caller then
+// launches k_channel_mix_draw itself).
+ChanHook g_chan_hook = {nullptr, nullptr};
 int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop);
 int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_stop) {
     Context &c = ctx();
+    const ChanHook none = {nullptr, nullptr};
+    auto take_hook = [&](bool reaches_root) {
+        if (!reaches_root || n_trees != 1 || !g_chan_hook.chan) return none;
+        const ChanHook h = g_chan_hook;
+        g_chan_hook = none;
+        return h;
+    };
     uint8_t *layers = (uint8_t *)ts.t[0];             // (the one-lane scheme kept for A/B timing handles one tree)
     static const bool one_lane = getenv("TSTWO_MERKLE_UP_ONELANE") != nullptr;     // previous scheme, kept for A/B timing
     static const bool small_wg = getenv("TSTWO_MERKLE_UP_SMALLWG") != nullptr;     // 256-lane workgroups only (A/B timing)
@@ -586,14 +664,14 @@ int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_sto
                 log_child -= remaining;
             }
         } else if (parents_log <= 8 && !small_wg) {   // <= 256 parents: ONE workgroup of 256 quads finishes the tree (up to 9 levels)
-            hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1, n_trees), dim3(1024), 0, c.stream, ts, log_child, remaining);
+            hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1, n_trees), dim3(1024), 0, c.stream, ts, log_child, remaining, take_hook(log_stop == 0));
             log_child -= remaining;
         } else if (parents_log >= 6) {            // >= 64 parents: 64 quads per workgroup, 64 -> 1 = up to 7 levels each
             u32 levels = remaining < 7 ? remaining : 7;
-            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1u << (parents_log - 6), n_trees), dim3(256), 0, c.stream, ts, log_child, levels);
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1u << (parents_log - 6), n_trees), dim3(256), 0, c.stream, ts, log_child, levels, none);
             log_child -= levels;
         } else {
-            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1, n_trees), dim3(256), 0, c.stream, ts, log_child, remaining);
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1, n_trees), dim3(256), 0, c.stream, ts, log_child, remaining, take_hook(log_stop == 0));
             log_child -= remaining;
         }
     }
@@ -606,61 +684,94 @@ int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop) {
     return commit_upper_levels(one, 1, log_child, log_stop);
 }
 
-// ---- Blake2sChannel on the device (channel/blake2.ts:25-224, Rust semantics).  State = 10 words: digest[8], n_challenges,
-// n_sent.  One quad of lanes runs the (latency-bound) compressions; used by the FRI commit loop so that a layer's root
-// never has to travel to the host before the next fold can be launched.
-__device__ __forceinline__ void chan_hash64(const u32 (&m)[16], u32 j, u32 (&digest)[8]) {
-    u32 lo, hi;
-    b2s_quad_block64(m, j, lo, hi);
-    // every lane of the quad needs the whole digest: word k lives in lane k & 3 (lo for k < 4, hi for k >= 4)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        digest[k] = (u32)__builtin_amdgcn_readlane((int)lo, k);
-        digest[4 + k] = (u32)__builtin_amdgcn_readlane((int)hi, k);
-    }
-}
-// mix_root (vcs/blake2_merkle.ts:28-31): digest <- H(digest || root), n_challenges += 1, n_sent <- 0; then (optionally)
-// draw_felt (blake2.ts:158-184): H(digest || LE32(n_sent) || 0^28) until all 8 words < 2P; felt = first 4 words reduced.
 __global__ void __launch_bounds__(64) k_channel_mix_draw(u32 *__restrict__ chan, const u32 *__restrict__ root, u32 *__restrict__ felt,
                                                         u32 do_mix, u32 do_draw) {
-    const u32 j = threadIdx.x & 3;
-    u32 d[8];
+    u32 d[8], f[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 8; k++) d[k] = chan[k];
     u32 n_chal = chan[8], n_sent = chan[9];
-    if (do_mix) {
-        u32 m[16];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { m[k] = d[k]; m[8 + k] = root[k]; }
-        chan_hash64(m, j, d);
-        n_chal += 1;
-        n_sent = 0;
-    }
-    if (do_draw) {
-        u32 w[8];
-        bool ok = false;
-        // retry probability per round ~ 2^-28; the loop is bounded so that the kernel always terminates (64 rejections in a
-        // row have probability 2^-1792)
-        for (int tries = 0; tries < 64 && !ok; tries++) {
-            u32 m[16];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { m[k] = d[k]; m[8 + k] = 0; }
-            m[8] = n_sent;
-            n_sent += 1;
-            chan_hash64(m, j, w);
-            ok = true;
-#pragma unroll
-            for (int k = 0; k < 8; k++) ok = ok && (w[k] < 2u * M31_P);
-        }
-        if (threadIdx.x < 4) {
-            u32 v = w[0];
-            v = threadIdx.x == 1 ? w[1] : v;
-            v = threadIdx.x == 2 ? w[2] : v;
-            v = threadIdx.x == 3 ? w[3] : v;
-            felt[threadIdx.x] = v >= M31_P ? v - M31_P : v;       // M31.reduce of a value < 2P
-        }
+    chan_mix_draw(d, n_chal, n_sent, root, do_mix != 0, do_draw != 0, f);
+    if (do_draw && threadIdx.x < 4) {
+        u32 v = f[0];
+        v = threadIdx.x == 1 ? f[1] : v;
+        v = threadIdx.x == 2 ? f[2] : v;
+        v = threadIdx.x == 3 ? f[3] : v;
+        felt[threadIdx.x] = v;
     }
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) chan[k] = d[k];
+        chan[8] = n_chal;
+        chan[9] = n_sent;
+    }
+}
+
+// ---- FRI commit tail: every layer from 2^log0 <= 2^9 rows down to the last one in ONE launch of one workgroup.  Per layer the
+// host loop costs three launches (tree, channel, fold) of a few microseconds of work each plus the gaps between dependent
+// kernels; here a layer is: the 4-column tree in LDS (leaves one per lane, levels by quads: the k_merkle_leaf4_upq body), the
+// channel's mix_root + draw_felt by wave 0 (state kept in its registers across the layers), fold_line by the first 2^(lg-1)
+// lanes.  Evaluations and trees go to the same buffers, in the same layouts, as the per-layer path.
+struct FriTail {
+    u32 *eval[11][4];        // eval[0]: the input evaluation (2^log0 rows, already folded); eval[i + 1]: output of fold i
+    uint4 *tree[10];         // tree[i]: layers buffer of the tree over eval[i]
+    u32 n_layers, log0;
+};
+__global__ void __launch_bounds__(1024) k_fri_tail(FriTail ft, const u32 *__restrict__ itw, u32 tw_log, u32 *__restrict__ chan,
+                                                  u32 *__restrict__ alphas) {
+    constexpr u32 Q = 256;
+    __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];
+    __shared__ u32 alpha_sh[4];
+    const u32 t = threadIdx.x;
+    u32 d[8], n_chal = 0, n_sent = 0;
+    if (t < 64) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = chan[k];
+        n_chal = chan[8]; n_sent = chan[9];
+    }
+    for (u32 i = 0; i < ft.n_layers; i++) {
+        const u32 lg = ft.log0 - i;                                  // 1 <= lg <= 9
+        const u32 *c0 = ft.eval[i][0], *c1 = ft.eval[i][1], *c2 = ft.eval[i][2], *c3 = ft.eval[i][3];
+        uint4 *layers = ft.tree[i];
+        // tree over the 4 coordinate columns (vcs/blake2_merkle.ts:9-24): leaves, then all levels
+        const u32 active = 1u << (lg - 1);
+        if (t < 2 * active) {
+            u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
+            const u32 m[16] = {gload1(c0 + t), gload1(c1 + t), gload1(c2 + t), gload1(c3 + t), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            b2s_compress(h, m, 16u, true);
+            uint4 *leaf = layers + 2 * ((((size_t)1 << lg) - 1) + t);
+            const uint4 lo = make_uint4(h[0], h[1], h[2], h[3]), hi = make_uint4(h[4], h[5], h[6], h[7]);
+            leaf[0] = lo; leaf[1] = hi;
+            reinterpret_cast<uint4 *>(sh)[2 * t] = lo;
+            reinterpret_cast<uint4 *>(sh)[2 * t + 1] = hi;
+        }
+        __syncthreads();
+        upq_levels<1024>(layers, sh, lg, lg, active);                // the root is in sh[0..7] afterwards
+        // channel: mix the root, draw alpha (wave 0; channel/blake2.ts:115-184, Rust draw semantics)
+        if (t < 64) {
+            u32 f[4];
+            chan_mix_draw(d, n_chal, n_sent, sh, true, true, f);
+            if (t < 4) {
+                const u32 v = t == 0 ? f[0] : t == 1 ? f[1] : t == 2 ? f[2] : f[3];
+                alpha_sh[t] = v;
+                alphas[4 * i + t] = v;
+            }
+        }
+        __syncthreads();
+        // fold_line (fri.ts:120-152): row r of the next evaluation
+        if (t < active) {
+            const qm31 alpha = {alpha_sh[0], alpha_sh[1], alpha_sh[2], alpha_sh[3]};
+            const u32 tw = itw[((size_t)1 << tw_log) - ((size_t)1 << lg) + t];
+            const uint2 a = gload2(c0 + 2 * t), b = gload2(c1 + 2 * t), c = gload2(c2 + 2 * t), e = gload2(c3 + 2 * t);
+            const qm31 f0 = {m31_add(a.x, a.y), m31_add(b.x, b.y), m31_add(c.x, c.y), m31_add(e.x, e.y)};
+            const qm31 f1 = qm31_mul_m31({m31_sub(a.x, a.y), m31_sub(b.x, b.y), m31_sub(c.x, c.y), m31_sub(e.x, e.y)}, tw);
+            const qm31 r = qm31_add(f0, qm31_mul(alpha, f1));
+            gstore1(ft.eval[i + 1][0] + t, r.a); gstore1(ft.eval[i + 1][1] + t, r.b);
+            gstore1(ft.eval[i + 1][2] + t, r.c); gstore1(ft.eval[i + 1][3] + t, r.d);
+        }
+        __threadfence();                 // the next layer's leaves are read by other lanes of this workgroup
+        __syncthreads();
+    }
+    if (t == 0) {
 #pragma unroll
         for (int k = 0; k < 8; k++) chan[k] = d[k];
         chan[8] = n_chal;
@@ -768,6 +879,33 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
 }
 
 }  // namespace
+
+namespace tstwo {
+// fri.hip's commit loop: tstwo_merkle_commit(…) followed by mix_root + draw_felt on its root, the channel step riding on the tree's
+// last launch when that launch is a single workgroup (every FRI layer's tree), a k_channel_mix_draw launch otherwise.
+int merkle_commit_then_channel(const u32 *const *cols, const u32 *log_sizes, size_t n_cols, uint8_t *layers, u32 *chan, u32 *felt) {
+    g_chan_hook = {chan, felt};
+    int rc = tstwo_merkle_commit(cols, log_sizes, n_cols, layers, nullptr);
+    const bool pending = g_chan_hook.chan != nullptr;
+    g_chan_hook = {nullptr, nullptr};
+    if (rc) return rc;
+    return pending ? tstwo_channel_mix_root_draw_felt(chan, layers, felt) : TSTWO_OK;
+}
+// fri.hip's commit loop hands the layers from 2^log0 <= 2^9 rows down to the last one to k_fri_tail (see there).
+int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas) {
+    if (n_layers == 0 || n_layers > 10 || log0 < n_layers || log0 > 9 || log0 - n_layers + 1 < 1)
+        return set_error(TSTWO_ERR_BAD_ARG, "fri tail: layer range out of bounds");
+    FriTail ft = {};
+    for (u32 i = 0; i <= n_layers; i++)
+        for (int k = 0; k < 4; k++) ft.eval[i][k] = eval[i][k];
+    for (u32 i = 0; i < n_layers; i++) ft.tree[i] = (uint4 *)trees[i];
+    ft.n_layers = n_layers;
+    ft.log0 = log0;
+    hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(1024), 0, ctx().stream, ft, itw, tw_log, chan, alphas);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+}  // namespace tstwo
 
 extern "C" {
 
@@ -1086,10 +1224,11 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
         Context &c = ctx();
         u32 log_child = max_log;
         if (max_log <= 9) {
-            hipLaunchKernelGGL(k_merkle_leaf4_upq<1024>, dim3(1), dim3(1024), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, max_log);
+            hipLaunchKernelGGL(k_merkle_leaf4_upq<1024>, dim3(1), dim3(1024), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, max_log, g_chan_hook);
+            g_chan_hook = {nullptr, nullptr};
             log_child = 0;
         } else {
-            hipLaunchKernelGGL(k_merkle_leaf4_upq<256>, dim3(1u << (max_log - 7)), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, 7u);
+            hipLaunchKernelGGL(k_merkle_leaf4_upq<256>, dim3(1u << (max_log - 7)), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, 7u, ChanHook{nullptr, nullptr});
             log_child = max_log - 7;
         }
         TSTWO_LAUNCH_CHECK();
