@@ -468,19 +468,23 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
     };
     size_t n = 0;
     static const bool no_tail = getenv("TSTWO_FRI_NO_TAIL") != nullptr;      // A/B timing: per-layer launches down to the last layer
+    uint8_t *cur_tree = nullptr;         // set: `cur` is already committed into it (its leaves were hashed by the fold that produced it)
+                                         // and alpha (n + 1) is drawn
+    uint8_t *spare_tree = nullptr;       // a tree buffer of the current size allocated for a fusion that an override refused
     while (cur_log > log_last_layer_size) {
-        if (!no_tail && cur_log <= 9 && nxt == n_columns) {
+        if (!cur_tree && !no_tail && cur_log <= 9 && nxt == n_columns) {
             // every remaining layer fits one workgroup's LDS: ONE launch does tree / mix / draw / fold for all of them (k_fri_tail)
             const u32 nl = cur_log - log_last_layer_size;
             u32 *ev[11][4];
             uint8_t *trees[10];
             for (int k = 0; k < 4; k++) ev[0][k] = cur[k];
             for (u32 i = 0; i < nl; i++) {
-                void *t = nullptr;
-                if ((rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log - i)))) return fail(rc);
+                void *t = i == 0 ? (void *)spare_tree : nullptr;
+                if (!t && (rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log - i)))) return fail(rc);
                 trees[i] = (uint8_t *)t;
                 if ((rc = alloc_eval(ev[i + 1], cur_log - i - 1))) return fail(rc);
             }
+            spare_tree = nullptr;
             if ((rc = launch_fri_tail(ev, trees, nl, cur_log, itw, tw_log, chan, alphas + 4 * (n + 1)))) return fail(rc);
             for (u32 i = 0; i < nl; i++) {
                 out[n].log_size = cur_log - i;
@@ -495,19 +499,41 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
         tstwo_fri_layer_out &o = out[n];
         o.log_size = cur_log;
         for (int k = 0; k < 4; k++) o.cols[k] = cur[k];
-        void *t = nullptr;
-        if ((rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log)))) return fail(rc);
-        o.layers = (uint8_t *)t;
-        const u32 lg4[4] = {cur_log, cur_log, cur_log, cur_log};
         alpha = alphas + 4 * (n + 1);
-        if ((rc = merkle_commit_then_channel(cur, lg4, 4, o.layers, chan, alpha))) return fail(rc);      // FriInnerLayerProver::new + mix / draw
+        if (cur_tree) {
+            o.layers = cur_tree;
+            cur_tree = nullptr;
+        } else {
+            void *t = spare_tree;
+            spare_tree = nullptr;
+            if (!t && (rc = alloc(&t, tstwo_merkle_layers_bytes(cur_log)))) return fail(rc);
+            o.layers = (uint8_t *)t;
+            const u32 lg4[4] = {cur_log, cur_log, cur_log, cur_log};
+            if ((rc = merkle_commit_then_channel(cur, lg4, 4, o.layers, chan, alpha))) return fail(rc);      // FriInnerLayerProver::new + mix / draw
+        }
+        // fold this layer.  When the folded evaluation is committed as it stands (no circle column joins it, the tail does not take
+        // it), the fold runs inside the leaf launch of ITS tree: the folded row is that tree's leaf message (merkle_commit4_folded)
+        const u32 next_log = cur_log - 1;
         u32 *folded[4];
-        if ((rc = alloc_eval(folded, cur_log - 1))) return fail(rc);
-        if ((rc = tstwo_fri_fold_line_dev(cur, cur_log, itw, tw_log, alpha, folded))) return fail(rc);
+        if ((rc = alloc_eval(folded, next_log))) return fail(rc);
+        const bool joins = nxt < n_columns && col_logs[nxt] - 1 == next_log;
+        const bool tail_next = !no_tail && next_log <= 9 && nxt + (joins ? 1 : 0) == n_columns;
+        bool fused = false;
+        if (next_log > log_last_layer_size && !joins && !tail_next) {
+            if (tw_log > 31 || cur_log > tw_log) return fail(set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!"));
+            void *t = nullptr;
+            if ((rc = alloc(&t, tstwo_merkle_layers_bytes(next_log)))) return fail(rc);
+            const u32 *seg = itw + ((size_t)1 << tw_log) - ((size_t)1 << cur_log);
+            rc = merkle_commit4_folded(cur, next_log, seg, alpha, folded, (uint8_t *)t, chan, alphas + 4 * (n + 2));
+            if (rc == -1) spare_tree = (uint8_t *)t;          // an environment override keeps 4-column trees off the leaf4 kernels
+            else if (rc) return fail(rc);
+            else { cur_tree = (uint8_t *)t; fused = true; }
+        }
+        if (!fused && (rc = tstwo_fri_fold_line_dev(cur, cur_log, itw, tw_log, alpha, folded))) return fail(rc);
         for (int k = 0; k < 4; k++) cur[k] = folded[k];
-        cur_log--;
+        cur_log = next_log;
         n++;
-        if (nxt < n_columns && col_logs[nxt] - 1 == cur_log)
+        if (joins)
             if ((rc = fold_circle_in())) return fail(rc);
     }
     if (nxt != n_columns) return fail(set_error(TSTWO_ERR_BAD_ARG, "not all columns were consumed"));      // Rust: assert!(columns.is_empty())

@@ -256,28 +256,57 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, Tr
     }
 }
 
+// fold_line fused into the leaf hashing of the NEXT FRI layer's tree (the folded row IS that tree's 16-byte leaf message,
+// vcs/blake2_merkle.ts:9-24 over the 4 coordinate columns): FoldSpec describes the layer being folded; the leaf kernels then
+// compute row i = f0 + alpha f1 from rows 2i, 2i+1 (fri.ts:120-152), store it to the new evaluation and hash it from registers.
+struct FoldSpec { const u32 *in[4]; const u32 *inv_x; const u32 *alpha; };       // alpha: 4 words in device memory (the drawn QM31)
+struct FoldRow { uint2 a, b, c, d; u32 t; };
+__device__ __forceinline__ FoldRow fold_row_load(const FoldSpec &fs, size_t i) {
+    return {gload2(fs.in[0] + 2 * i), gload2(fs.in[1] + 2 * i), gload2(fs.in[2] + 2 * i), gload2(fs.in[3] + 2 * i), gload1(fs.inv_x + i)};
+}
+__device__ __forceinline__ qm31 fold_row(const FoldRow &r, qm31 alpha) {
+    const qm31 f0 = {m31_add(r.a.x, r.a.y), m31_add(r.b.x, r.b.y), m31_add(r.c.x, r.c.y), m31_add(r.d.x, r.d.y)};
+    const qm31 f1 = qm31_mul_m31({m31_sub(r.a.x, r.a.y), m31_sub(r.b.x, r.b.y), m31_sub(r.c.x, r.c.y), m31_sub(r.d.x, r.d.y)}, r.t);
+    return qm31_add(f0, qm31_mul(alpha, f1));
+}
+
 // (1b) bottom layer of exactly 4 columns — every FRI layer (the 4 coordinate columns of a QM31 column): a 16-byte
 //      message, one final block whose words 4..15 are zero.
-__global__ void __launch_bounds__(256) k_merkle_leaf4(const u32 *__restrict__ c0, const u32 *__restrict__ c1, const u32 *__restrict__ c2,
-                                                     const u32 *__restrict__ c3, uint4 *__restrict__ out, size_t n_nodes) {
+template <bool FOLD>
+__global__ void __launch_bounds__(256) k_merkle_leaf4(u32 *__restrict__ c0, u32 *__restrict__ c1, u32 *__restrict__ c2, u32 *__restrict__ c3,
+                                                     uint4 *__restrict__ out, size_t n_nodes, FoldSpec fs) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 rows = (u32)((n_nodes + stride - 1) / stride);
     const size_t last_node = n_nodes - 1;
     auto word = [&](const u32 *col, u32 byte_off) -> u32 { return *(const TSTWO_GLOBAL u32 *)((const TSTWO_GLOBAL char *)col + byte_off); };
     const u32 o0 = (u32)min(node0, last_node) * 4u;       // scalar base + one 32-bit offset (log_size <= 30: host)
-    u32 a = word(c0, o0), b = word(c1, o0), c = word(c2, o0), d = word(c3, o0);
+    u32 a = 0, b = 0, c = 0, d = 0;
+    FoldRow fr = {};
+    qm31 alpha = {0, 0, 0, 0};
+    if (FOLD) {
+        alpha = {fs.alpha[0], fs.alpha[1], fs.alpha[2], fs.alpha[3]};
+        fr = fold_row_load(fs, min(node0, last_node));
+    } else {
+        a = word(c0, o0); b = word(c1, o0); c = word(c2, o0); d = word(c3, o0);
+    }
     u32 hp[8] = {0, 0, 0, 0, 0, 0, 0, 0};                        // deferred store: see k_merkle_leaf_static
     size_t pnode = n_nodes;
     for (u32 j = 0; j < rows; j++) {
         const size_t node = node0 + (size_t)j * stride;
         const size_t nn = min(node + stride, last_node);
         const u32 on = (u32)nn * 4u;
+        u32 na = 0, nb = 0, ncc = 0, nd = 0;
+        FoldRow nfr = {};
+        if (FOLD) {
+            nfr = fold_row_load(fs, nn);                             // next node's rows in flight during the compression
+        } else {
 #ifdef TSTWO_EXP_L4_NOLOAD       // experiment: ALU + stores only (WRONG results)
-        const u32 na = a + on, nb = b ^ on, ncc = c + 1u, nd = d + on;
+            na = a + on; nb = b ^ on; ncc = c + 1u; nd = d + on;
 #else
-        const u32 na = word(c0, on), nb = word(c1, on), ncc = word(c2, on), nd = word(c3, on);      // next node's words in flight during the compression
+            na = word(c0, on); nb = word(c1, on); ncc = word(c2, on); nd = word(c3, on);      // next node's words in flight during the compression
 #endif
+        }
 #ifdef TSTWO_EXP_L4_NOSTORE      // experiment: (practically) no stores (WRONG results)
         if (pnode < n_nodes && hp[0] == 0x12345678u && hp[1] == 0x9abcdef0u) {
 #else
@@ -286,13 +315,19 @@ __global__ void __launch_bounds__(256) k_merkle_leaf4(const u32 *__restrict__ c0
             out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
             out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
         }
+        if (FOLD) {
+            const qm31 r = fold_row(fr, alpha);
+            a = r.a; b = r.b; c = r.c; d = r.d;
+            if (node < n_nodes) { gstore1(c0 + node, a); gstore1(c1 + node, b); gstore1(c2 + node, c); gstore1(c3 + node, d); }
+        }
         u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
         const u32 m[16] = {a, b, c, d, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         b2s_compress(h, m, 16u, true);
 #pragma unroll
         for (int k = 0; k < 8; k++) hp[k] = h[k];
         pnode = node;
-        a = na; b = nb; c = ncc; d = nd;
+        if (FOLD) fr = nfr;
+        else { a = na; b = nb; c = ncc; d = nd; }
     }
     if (pnode < n_nodes) {
         out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
@@ -610,9 +645,9 @@ __global__ void __launch_bounds__(WG) k_merkle_upq(TreeSet ts, u32 log_child, u3
 // A small 4-column tree (every FRI layer below 2^17 rows) without a launch of its own for the leaves: the first 2*active lanes
 // of the workgroup hash one leaf each (16-byte message, vcs/blake2_merkle.ts:9-24), write it to the leaf layer and to LDS,
 // and the quad levels follow in the same launch.
-template <int WG>
-__global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__ c0, const u32 *__restrict__ c1, const u32 *__restrict__ c2,
-                                                        const u32 *__restrict__ c3, uint4 *__restrict__ layers, u32 log_leaf, u32 levels, ChanHook hk) {
+template <int WG, bool FOLD>
+__global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(u32 *__restrict__ c0, u32 *__restrict__ c1, u32 *__restrict__ c2, u32 *__restrict__ c3,
+                                                        uint4 *__restrict__ layers, u32 log_leaf, u32 levels, ChanHook hk, FoldSpec fs) {
     constexpr u32 Q = WG / 4;
     __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];
     const u32 t = threadIdx.x;
@@ -620,7 +655,15 @@ __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__
     if (t < 2 * active) {
         const size_t node = (size_t)blockIdx.x * (2 * active) + t;
         u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
-        const u32 m[16] = {c0[node], c1[node], c2[node], c3[node], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        u32 m0, m1, m2, m3;
+        if (FOLD) {
+            const qm31 r = fold_row(fold_row_load(fs, node), {fs.alpha[0], fs.alpha[1], fs.alpha[2], fs.alpha[3]});
+            m0 = r.a; m1 = r.b; m2 = r.c; m3 = r.d;
+            gstore1(c0 + node, m0); gstore1(c1 + node, m1); gstore1(c2 + node, m2); gstore1(c3 + node, m3);
+        } else {
+            m0 = c0[node]; m1 = c1[node]; m2 = c2[node]; m3 = c3[node];
+        }
+        const u32 m[16] = {m0, m1, m2, m3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         b2s_compress(h, m, 16u, true);
         uint4 *leaf = layers + 2 * ((((size_t)1 << log_leaf) - 1) + node);
         const uint4 lo = make_uint4(h[0], h[1], h[2], h[3]), hi = make_uint4(h[4], h[5], h[6], h[7]);
@@ -638,6 +681,10 @@ __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(const u32 *__restrict__
 // channel step with it and clears the hook; a hook still set afterwards means the tree went another way (the caller then
 // launches k_channel_mix_draw itself).
 ChanHook g_chan_hook = {nullptr, nullptr};
+// Likewise for a fold: set by merkle_commit4_folded around a tstwo_merkle_commit of the 4 NEW coordinate columns; the leaf launch
+// of that tree folds the previous layer into them on the way (FoldSpec) and clears it.
+FoldSpec g_fold = {};
+bool g_fold_set = false;
 int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop);
 int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_stop) {
     Context &c = ctx();
@@ -833,7 +880,13 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
         return TSTWO_OK;
     }
     if (!prev && log_size <= 30 && n_cols == 4 && !getenv("TSTWO_MERKLE_GENERIC")) {
-        hipLaunchKernelGGL(k_merkle_leaf4, dim3(blocks), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)out, n_nodes);
+        u32 *w0 = const_cast<u32 *>(cols[0]), *w1 = const_cast<u32 *>(cols[1]), *w2 = const_cast<u32 *>(cols[2]), *w3 = const_cast<u32 *>(cols[3]);
+        if (g_fold_set) {
+            hipLaunchKernelGGL(k_merkle_leaf4<true>, dim3(blocks), dim3(256), 0, c.stream, w0, w1, w2, w3, (uint4 *)out, n_nodes, g_fold);
+            g_fold_set = false;
+        } else {
+            hipLaunchKernelGGL(k_merkle_leaf4<false>, dim3(blocks), dim3(256), 0, c.stream, w0, w1, w2, w3, (uint4 *)out, n_nodes, FoldSpec{});
+        }
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
     }
@@ -890,6 +943,24 @@ int merkle_commit_then_channel(const u32 *const *cols, const u32 *log_sizes, siz
     g_chan_hook = {nullptr, nullptr};
     if (rc) return rc;
     return pending ? tstwo_channel_mix_root_draw_felt(chan, layers, felt) : TSTWO_OK;
+}
+// fri.hip's commit loop: fold_line of a layer INTO the leaf hashing of the next layer's tree.  new_cols (2^log_new rows each) receive
+// the folded evaluation; `layers` the tree over them; then mix_root + draw_felt as in merkle_commit_then_channel.  Bit-identical to
+// tstwo_fri_fold_line_dev + tstwo_merkle_commit + tstwo_channel_mix_root_draw_felt (which it falls back to when an environment
+// override routes 4-column trees away from the leaf4 kernels).
+int merkle_commit4_folded(const u32 *const prev[4], u32 log_new, const u32 *inv_x, const u32 *alpha_dev, u32 *const new_cols[4],
+                          uint8_t *layers, u32 *chan, u32 *felt) {
+    const bool fusable = !getenv("TSTWO_MERKLE_GENERIC") && !getenv("TSTWO_MERKLE_NO_FUSED_LEAF4") && !getenv("TSTWO_FRI_NO_FOLD_FUSION") && log_new >= 1 &&
+                         log_new <= 30;
+    const u32 lg4[4] = {log_new, log_new, log_new, log_new};
+    if (!fusable) return -1;                                     // caller takes the unfused path
+    g_fold = {{prev[0], prev[1], prev[2], prev[3]}, inv_x, alpha_dev};
+    g_fold_set = true;
+    int rc = merkle_commit_then_channel(new_cols, lg4, 4, layers, chan, felt);
+    const bool consumed = !g_fold_set;
+    g_fold_set = false;
+    if (rc) return rc;
+    return consumed ? TSTWO_OK : set_error(TSTWO_ERR_HIP, "fri commit: the fold was not carried by the leaf launch");
 }
 // fri.hip's commit loop hands the layers from 2^log0 <= 2^9 rows down to the last one to k_fri_tail (see there).
 int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas) {
@@ -1223,12 +1294,18 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
         log_sizes[3] == max_log && !getenv("TSTWO_MERKLE_NO_FUSED_LEAF4")) {
         Context &c = ctx();
         u32 log_child = max_log;
+        u32 *w0 = const_cast<u32 *>(cols[0]), *w1 = const_cast<u32 *>(cols[1]), *w2 = const_cast<u32 *>(cols[2]), *w3 = const_cast<u32 *>(cols[3]);
+        const bool fold = g_fold_set;
+        const FoldSpec fs = fold ? g_fold : FoldSpec{};
+        g_fold_set = false;
         if (max_log <= 9) {
-            hipLaunchKernelGGL(k_merkle_leaf4_upq<1024>, dim3(1), dim3(1024), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, max_log, g_chan_hook);
+            if (fold) hipLaunchKernelGGL((k_merkle_leaf4_upq<1024, true>), dim3(1), dim3(1024), 0, c.stream, w0, w1, w2, w3, (uint4 *)layers, max_log, max_log, g_chan_hook, fs);
+            else hipLaunchKernelGGL((k_merkle_leaf4_upq<1024, false>), dim3(1), dim3(1024), 0, c.stream, w0, w1, w2, w3, (uint4 *)layers, max_log, max_log, g_chan_hook, fs);
             g_chan_hook = {nullptr, nullptr};
             log_child = 0;
         } else {
-            hipLaunchKernelGGL(k_merkle_leaf4_upq<256>, dim3(1u << (max_log - 7)), dim3(256), 0, c.stream, cols[0], cols[1], cols[2], cols[3], (uint4 *)layers, max_log, 7u, ChanHook{nullptr, nullptr});
+            if (fold) hipLaunchKernelGGL((k_merkle_leaf4_upq<256, true>), dim3(1u << (max_log - 7)), dim3(256), 0, c.stream, w0, w1, w2, w3, (uint4 *)layers, max_log, 7u, ChanHook{nullptr, nullptr}, fs);
+            else hipLaunchKernelGGL((k_merkle_leaf4_upq<256, false>), dim3(1u << (max_log - 7)), dim3(256), 0, c.stream, w0, w1, w2, w3, (uint4 *)layers, max_log, 7u, ChanHook{nullptr, nullptr}, fs);
             log_child = max_log - 7;
         }
         TSTWO_LAUNCH_CHECK();
