@@ -38,6 +38,12 @@ $T 300 python3 tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err
 echo "configs done"
 $T 300 python3 tools/bench_callers.py > $O/callers.jsonl 2> $O/callers.err
 echo "callers done"
+$T 300 python3 tools/bench_fri_sizes.py > $O/fri_sizes.log 2>&1
+echo "fri sizes done"
+# the N = 2 control flow of the strong-scaling bench on the one GPU (roots through the host) and the RCCL path at world size 1
+TSTWO_BENCH_COLLECTIVE=gloo $T 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-configs > $O/bench_gloo2_rehearsal.json 2> $O/bench_gloo2.err
+TSTWO_FORCE_DIST=1 $T 300 python3 bench.py --steps 5 --warmup 2 --no-configs --no-cpu --no-pmc > $O/bench_rccl_world1.json 2> $O/bench_rccl1.err
+echo "rehearsals done"
 rm -rf $O/stats $O/stats_configs $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces are large; summaries are what is kept
 ls -la $O
 sha256sum $R/tstwo_amd/libtstwo_hip.so | cut -c1-16 > $O/lib_sha16.txt
