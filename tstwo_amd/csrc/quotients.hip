@@ -6,8 +6,9 @@
 //         = sum_j c_j * f_{col_j}(r)  -  (A_b * p.y + B_b),   A_b = sum_j a_j, B_b = sum_j b_j   (exact)
 //   acc   = acc * coeff_b + num_b * den_b^-1
 //
-// One lane owns 8 consecutive rows.  In bit-reversed order those are p0, conj p0, -p0, conj -p0,
-// p0+Q, ..., with Q the order-4 point, so one double-and-add per lane (amortised to <= 11 M31
+// One lane owns two quads of 4 consecutive rows.  In bit-reversed order a quad is p0, conj p0, -p0, conj -p0 and the
+// second quad is the same around p0 + Q (Q a fixed point: the quads lie 2^bsel rows apart, chosen so that a wave's loads
+// cover whole cache lines), so one double-and-add per lane (amortised to <= 11 M31
 // multiplications per row) replaces the reference's per-row scalar multiplication, and the 8
 // denominators of a batch share one Montgomery inversion (the unique inverse, same value as the
 // reference's per-row batchInverse).  Constants are tiny and wave-uniform (scalar loads).
@@ -34,8 +35,8 @@ struct Entry {               // 8 words
     u32 pad[3];
 };
 
-// One lane = 8 consecutive rows = the points p0, conj p0, -p0, conj -p0, p1, conj p1, -p1, conj -p1 with p1 = p0 + Q4
-// (bit-reversed order; Q4 the order-4 point): row s has x = sx[s] * x_{s>>2}, y = sy[s] * y_{s>>2}, sx = + + - -, sy = + - - +.
+// One lane = 8 rows = the points p0, conj p0, -p0, conj -p0, p1, conj p1, -p1, conj -p1 with p1 = p0 + Q
+// (bit-reversed order; Q the point 2^bsel rows away): row s has x = sx[s] * x_{s>>2}, y = sy[s] * y_{s>>2}, sx = + + - -, sy = + - - +.
 // Everything below is the same operation on the 8 rows, issued in priority phases (field8.cuh), and uses the signs:
 //   * numerator  sum_j c_j f_j(row): lazily in 64 bits, 4 column entries per reduction (4 units of (P-1)P);
 //   * A p.y + B and the denominator  C0 + x (P - Pi.y) + y Pi.x  need the products with x0, x1, y0, y1 only (8 + 8
@@ -52,19 +53,26 @@ __device__ __forceinline__ void bcast(T (&r)[8], T v) {
 
 // SINGLE: one sample batch (the common shape: BASELINE config 3) — a half's rows go straight to memory; otherwise the
 // accumulator of all 8 rows lives in registers across the batches (32 more VGPRs).
-template <bool SINGLE>
+// LAZY: some batch has more than 4 column entries — the numerator's 64-bit sums are folded, not reduced, between groups of 4.
+template <bool SINGLE, bool LAZY>
 __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
                                                    const BatchConst *__restrict__ batches, u32 n_batches,
                                                    const Entry *__restrict__ entries, Soa4 out,
-                                                   const cpoint *__restrict__ gen_pow2, cpoint q4, u32 *flag) {
+                                                   const cpoint *__restrict__ gen_pow2, cpoint qb, u32 bsel, u32 *flag) {
     const size_t n_threads = (size_t)1 << (log_size - 3);
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_threads) return;
-    // natural index of row 8t: bitrev(t, log_size-3) inside the half coset (log_size-1), step 2^(31-(log_size-1))
-    u32 bt = log_size > 3 ? (__brev((u32)t) >> (32 - (log_size - 3))) : 0u;
-    u32 idx0 = (half_initial + (bt << (32 - log_size))) & 0x7fffffffu;
+    // The lane's two quads of rows: 4t with a zero bit inserted at position bsel, and that + 2^bsel.  bsel = 8 (domains of at
+    // least 512 rows): a wave's 64 quads A are 1 KiB of consecutive rows and so are its quads B — every 16-byte load and store
+    // of the wave covers whole cache lines (with bsel = 2, 8 consecutive rows per lane, each access used half of every line
+    // and the other half was fetched again later: at 32 columns the lines did not survive in L2 in between).
+    // Row r sits at natural index bitrev(r): row bit k >= 1 moves the point by 2^(31-k) generator steps (k = 1: -p, k = bsel: + qb).
+    // (rows as 32-bit word offsets from wave-uniform column bases: log_size <= 30, checked by the host)
+    const u32 u4 = (u32)t << 2;
+    const u32 rowA = ((u4 >> bsel) << (bsel + 1)) | (u4 & ((1u << bsel) - 1u)), rowB = rowA + (1u << bsel);
+    u32 idx0 = (half_initial + __brev(rowA)) & 0x7fffffffu;
     const cpoint p0 = cpoint_from_index_win(idx0, gen_pow2);      // gen_pow2 = Context::gen_win for this kernel
-    const cpoint p1 = cpoint_add(p0, q4);
+    const cpoint p1 = cpoint_add(p0, qb);
     u32 xy[8] = {p0.x, p1.x, p0.y, p1.y, p0.x, p1.x, p0.y, p1.y};        // operands of the denominator products (a | b halves)
     u32 yy[8] = {p0.y, p0.y, p0.y, p0.y, p1.y, p1.y, p1.y, p1.y};        // operands of A * y
 
@@ -74,7 +82,6 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
         for (int k = 0; k < 4; k++) bcast(acc[SINGLE ? 0 : k], 0u);
     }
     bool zero = false;
-    const size_t row0 = t << 3;
 
     for (u32 b = 0; b < n_batches; b++) {
         const BatchConst bc = batches[b];
@@ -121,37 +128,81 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             u32 num[2][8];
-            bool first = true;
-            for (u32 j = bc.begin; j < bc.end; j += 4) {
-                const u32 cnt = min(4u, bc.end - j);                    // wave-uniform
-                u32 cw[4][4], f[4][4];
+            if constexpr (LAZY) {
+                // running 64-bit sums, [coordinate 2h of the 4 rows | coordinate 2h + 1 of the 4 rows].  A group of 4 column entries adds 4
+                // products of < 2^62; between groups the sum is FOLDED, not reduced: x = lo + 2^32 hi = lo + 2 hi (mod P, 2^31 = 1) is one
+                // multiply-add (hi * 2 + lo < 2^34), after which four more products fit again (4 (P-1)^2 + 2^34 < 2^64).  One full
+                // reduction (13 instructions) per coordinate and row at the end instead of one per group: with 32 sampled columns the
+                // reductions were three quarters of the kernel's instructions.
+                u64 accq[2][8];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const Entry en = entries[j + (e < (int)cnt ? e : 0)];          // loads are never branched around; unused products get c = 0
-                    const uint4 fv = gload4(cols[en.col] + row0 + 4 * half);
-                    f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
-                    const bool on = e < (int)cnt;
-                    cw[e][0] = on ? en.c.a : 0u; cw[e][1] = on ? en.c.b : 0u; cw[e][2] = on ? en.c.c : 0u; cw[e][3] = on ? en.c.d : 0u;
-                }
-                u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
-                                {f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]}};
+                for (int s = 0; s < 8; s++) accq[0][s] = accq[1][s] = 0ull;
+                u32 two = 2u;                                   // in a VGPR: hi * two + lo stays ONE v_mad_u64_u32 (a literal 2 becomes shift + add-with-carry)
+                asm volatile("" : "+v"(two));
+                for (u32 j = bc.begin; j < bc.end; j += 4) {
+                    const u32 cnt = min(4u, bc.end - j);                    // wave-uniform
+                    u32 cw[4][4], f[4][4];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    u64 a64[8];
+                    for (int e = 0; e < 4; e++) {
+                        const Entry en = entries[j + (e < (int)cnt ? e : 0)];          // loads are never branched around; unused products get c = 0
+                        const uint4 fv = gload4(cols[en.col], half ? rowB : rowA);
+                        f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
+                        const bool on = e < (int)cnt;
+                        cw[e][0] = on ? en.c.a : 0u; cw[e][1] = on ? en.c.b : 0u; cw[e][2] = on ? en.c.c : 0u; cw[e][3] = on ? en.c.d : 0u;
+                    }
+                    u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
+                                    {f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]}};
                     f8::boundary<kPrioHeavy>(fp[0], fp[1]);
 #pragma unroll
-                    for (int s = 0; s < 8; s++) {           // up to 4 products of < 2^62 plus the 31-bit running value
-                        const int k = 2 * h + (s >> 2), r = s & 3;
-                        u64 a = first ? 0ull : (u64)num[h][s];
+                    for (int h = 0; h < 2; h++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) a += (u64)cw[e][k] * (u64)fp[e >> 1][4 * (e & 1) + r];
-                        a64[s] = a;
-                    }
-                    f8::reduce(num[h], a64);
+                        for (int s = 0; s < 8; s++) {
+                            const int k = 2 * h + (s >> 2), r = s & 3;
+                            u64 a = (u64)(u32)(accq[h][s] >> 32) * (u64)two + (u64)(u32)accq[h][s];          // the fold (0 stays 0)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) a += (u64)cw[e][k] * (u64)fp[e >> 1][4 * (e & 1) + r];
+                            accq[h][s] = a;
+                        }
+                    f8::pin(accq[0]); f8::pin(accq[1]);
+                    f8::done();
                 }
-                first = false;
+                f8::reduce(num[0], accq[0]);
+                f8::reduce(num[1], accq[1]);
+
+            } else {
+                // at most 4 column entries per batch (BASELINE config 3): one group, reduced directly
+                bool first = true;
+                for (u32 j = bc.begin; j < bc.end; j += 4) {
+                    const u32 cnt = min(4u, bc.end - j);                    // wave-uniform
+                    u32 cw[4][4], f[4][4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const Entry en = entries[j + (e < (int)cnt ? e : 0)];          // loads are never branched around; unused products get c = 0
+                        const uint4 fv = gload4(cols[en.col], half ? rowB : rowA);
+                        f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
+                        const bool on = e < (int)cnt;
+                        cw[e][0] = on ? en.c.a : 0u; cw[e][1] = on ? en.c.b : 0u; cw[e][2] = on ? en.c.c : 0u; cw[e][3] = on ? en.c.d : 0u;
+                    }
+                    u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
+                                    {f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]}};
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        u64 a64[8];
+                        f8::boundary<kPrioHeavy>(fp[0], fp[1]);
+#pragma unroll
+                        for (int s = 0; s < 8; s++) {           // up to 4 products of < 2^62 plus the 31-bit running value
+                            const int k = 2 * h + (s >> 2), r = s & 3;
+                            u64 a = first ? 0ull : (u64)num[h][s];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) a += (u64)cw[e][k] * (u64)fp[e >> 1][4 * (e & 1) + r];
+                            a64[s] = a;
+                        }
+                        f8::reduce(num[h], a64);
+                    }
+                    first = false;
+                }
+                if (first) { bcast(num[0], 0u); bcast(num[1], 0u); }
             }
-            if (first) { bcast(num[0], 0u); bcast(num[1], 0u); }
             u32 term[2][8];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -185,8 +236,8 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
             if (SINGLE) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    gstore4(out.p[2 * h] + row0 + 4 * half, make_uint4(term[h][0], term[h][1], term[h][2], term[h][3]));
-                    gstore4(out.p[2 * h + 1] + row0 + 4 * half, make_uint4(term[h][4], term[h][5], term[h][6], term[h][7]));
+                    gstore4(out.p[2 * h], half ? rowB : rowA, make_uint4(term[h][0], term[h][1], term[h][2], term[h][3]));
+                    gstore4(out.p[2 * h + 1], half ? rowB : rowA, make_uint4(term[h][4], term[h][5], term[h][6], term[h][7]));
                 }
             } else if (b == 0) {              // the accumulator is zero before the first batch
 #pragma unroll
@@ -208,8 +259,8 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
     if (!SINGLE) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            gstore4(out.p[k] + row0, make_uint4(acc[SINGLE ? 0 : k][0], acc[SINGLE ? 0 : k][1], acc[SINGLE ? 0 : k][2], acc[SINGLE ? 0 : k][3]));
-            gstore4(out.p[k] + row0 + 4, make_uint4(acc[SINGLE ? 0 : k][4], acc[SINGLE ? 0 : k][5], acc[SINGLE ? 0 : k][6], acc[SINGLE ? 0 : k][7]));
+            gstore4(out.p[k], rowA, make_uint4(acc[SINGLE ? 0 : k][0], acc[SINGLE ? 0 : k][1], acc[SINGLE ? 0 : k][2], acc[SINGLE ? 0 : k][3]));
+            gstore4(out.p[k], rowB, make_uint4(acc[SINGLE ? 0 : k][4], acc[SINGLE ? 0 : k][5], acc[SINGLE ? 0 : k][6], acc[SINGLE ? 0 : k][7]));
         }
     }
 }
@@ -310,17 +361,23 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
     bool aligned = true;
     for (int k = 0; k < 4; k++) aligned = aligned && ((((uintptr_t)out[k]) & 15) == 0);
-    if (log_size >= 3 && aligned) {
+    if (log_size >= 3 && log_size <= 30 && aligned) {
+        const u32 bsel = log_size >= 9 ? 8u : 2u;          // row bit that separates a lane's two quads (k_quotients8)
         u32 qx, qy;
-        host::point(1u << 29, &qx, &qy);   // order-4 point
-        cpoint q4 = {qx, qy};
+        host::point(1u << (31 - bsel), &qx, &qy);
+        cpoint qb = {qx, qy};
         size_t n_threads = (size_t)1 << (log_size - 3);
-        if (n_batches == 1)
-            hipLaunchKernelGGL(k_quotients8<true>, dim3(ceil_div(n_threads, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu,
-                               log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_win, q4, c.flag);
-        else
-            hipLaunchKernelGGL(k_quotients8<false>, dim3(ceil_div(n_threads, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu,
-                               log_size, d_cols, d_b, (u32)n_batches, d_e, o4, c.gen_win, q4, c.flag);
+        bool lazy = false;               // a batch with more than 4 column entries: fold the numerator sums between groups
+        static const bool no_lazy = getenv("TSTWO_QUOT_NO_LAZY") != nullptr;          // (measurement knob: reduce after every group of 4)
+        for (size_t b = 0; b < n_batches; b++) lazy = lazy || (!no_lazy && batch_off[b + 1] - batch_off[b] > 4);
+        const dim3 grid(ceil_div(n_threads, 256));
+#define TSTWO_QLAUNCH(S, Z) hipLaunchKernelGGL((k_quotients8<S, Z>), grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, d_cols, d_b, \
+                                               (u32)n_batches, d_e, o4, c.gen_win, qb, bsel, c.flag)
+        if (n_batches == 1 && lazy) TSTWO_QLAUNCH(true, true);
+        else if (n_batches == 1) TSTWO_QLAUNCH(true, false);
+        else if (lazy) TSTWO_QLAUNCH(false, true);
+        else TSTWO_QLAUNCH(false, false);
+#undef TSTWO_QLAUNCH
     } else {
         size_t N = (size_t)1 << log_size;
         hipLaunchKernelGGL(k_quotients_row, dim3(ceil_div(N, 256)), dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size,
