@@ -272,10 +272,14 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu
     cols_host = splitmix_columns([100 + c for c in my_cols], N)
     dev_cols = []
+    L.sync()
+    t_up = time.perf_counter()
     for h in cols_host:
         b = L.DeviceBuffer(4 * N)
         b.upload(h)
         dev_cols.append(b)
+    L.sync()
+    t_up = time.perf_counter() - t_up                      # host -> device hand-over of the rank's columns (tstwo_col_upload from pageable numpy arrays): reported, never in `value`
     if not want_cpu:
         cols_host = None
     col_ptrs = L.ptr_array([b.ptr for b in dev_cols])
@@ -458,6 +462,11 @@ def main():
                                   "frac_of_measured_peak": valu_rate / VALU_PEAK_MEASURED,
                                   "dual_issue_peak_lane_ops_per_s": VALU_PEAK_DUAL_MEASURED,
                                   "frac_of_dual_issue_peak": valu_rate / VALU_PEAK_DUAL_MEASURED}},
+            # What a caller pays who hands the trace over from host memory on every step (the design does not: columns stay
+            # resident from evaluate to the folds).  Measured on this run's own upload of the rank's columns; never `value`.
+            "host_boundary": {"h2d_seconds": t_up, "h2d_bytes": 4.0 * N * n_cols, "h2d_GBps": 4.0 * N * n_cols / t_up / 1e9,
+                              "source": "pageable numpy arrays through tstwo_col_upload, one call per column",
+                              "pcie_inclusive_elems_per_s": n_cols * N / (t_up + elapsed / steps)},
             "device": L.device_name(),
         }
         root_ok = None
