@@ -74,6 +74,12 @@ int tstwo_set_alloc_mode(int mode);
  * uploads travel through a page-locked ring without a host synchronisation, large ones synchronise). */
 int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
+/* n_pieces small device buffers in one round trip: piece i = n_bytes[i] bytes (whole 4-byte aligned words) at srcs[i]; the pieces
+ * land back to back in host_out.  Up to 256 KiB in all they are packed on the device into page-locked host memory and cost one
+ * stream synchronisation (the read-backs that end a FRI commit — channel state, the last layer's four coordinate columns
+ * `LineEvaluation.interpolate` wants on the host, poly/line.ts:312-329 — took six); larger requests are fetched piece by piece.
+ * srcs / n_bytes are host arrays.  Synchronous. */
+int tstwo_download_many(const void *const *srcs, const size_t *n_bytes, size_t n_pieces, void *host_out);
 int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes);        /* async d2d */
 int tstwo_zero(void *dev, size_t bytes);                                  /* async; Column.zeros, backend/index.ts:56 */
 /* hipGraph capture of a launch sequence (launch-bound loops: e.g. the 20+ small kernels of a FRI commit with the device

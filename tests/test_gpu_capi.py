@@ -876,3 +876,34 @@ def test_merkle_commit_many_mixed_shapes_and_errors():
     L.call("tstwo_merkle_commit_many", reqs, 0, None)                 # nothing to do
     with pytest.raises(L.TstwoError, match="null request table"):
         L.call("tstwo_merkle_commit_many", None, 2, roots)
+
+
+@pytest.mark.parametrize("sizes", [[10], [10, 16, 16, 16, 16, 16], [1, 0, 3, 70000, 5], list(range(1, 40)), [40000, 40000, 7]], ids=str)
+def test_download_many_equals_downloads_one_by_one(sizes):
+    """tstwo_download_many: the pieces back to back, byte-identical to one tstwo_download per piece — through the mapped result
+    page (up to 256 KiB, more than 16 pieces = several packing launches) and through the piece-by-piece path above it."""
+    rng = np.random.default_rng(sum(sizes))
+    hosts = [rng.integers(0, 2**32, size=max(w, 1), dtype=np.uint32) for w in sizes]
+    bufs = [dev(h) for h in hosts]
+    got = L.download_many([(b.ptr, w) for b, w in zip(bufs, sizes)])
+    assert len(got) == len(sizes)
+    for g, h, w in zip(got, hosts, sizes):
+        assert np.array_equal(g, h[:w])
+    # a slice in the middle of a buffer (word-aligned offset)
+    if sizes[0] >= 10:
+        (mid,) = L.download_many([(bufs[0].ptr + 12, 5)])
+        assert np.array_equal(mid, hosts[0][3:8])
+
+
+def test_download_many_errors():
+    b = dev(np.arange(8, dtype=np.uint32))
+    out = np.zeros(8, dtype=np.uint32)
+    srcs = (C.c_void_p * 1)(b.ptr)
+    with pytest.raises(L.TstwoError, match="whole, 4-byte aligned words"):
+        L.call("tstwo_download_many", srcs, (C.c_size_t * 1)(6), 1, out.ctypes.data_as(C.c_void_p))
+    with pytest.raises(L.TstwoError, match="whole, 4-byte aligned words"):
+        L.call("tstwo_download_many", (C.c_void_p * 1)(b.ptr + 2), (C.c_size_t * 1)(8), 1, out.ctypes.data_as(C.c_void_p))
+    with pytest.raises(L.TstwoError, match="null argument"):
+        L.call("tstwo_download_many", srcs, (C.c_size_t * 1)(8), 1, C.c_void_p(0))
+    L.call("tstwo_download_many", srcs, (C.c_size_t * 1)(0), 1, out.ctypes.data_as(C.c_void_p))       # nothing to fetch: fine
+    assert len(L.download_many([])) == 0

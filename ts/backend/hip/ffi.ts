@@ -30,6 +30,7 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_free: { args: [u64], returns: i32 },
   tstwo_upload: { args: [u64, P, u64], returns: i32 },
   tstwo_download: { args: [P, u64, u64], returns: i32 },
+  tstwo_download_many: { args: [P, P, u64, P], returns: i32 },
   tstwo_copy: { args: [u64, u64, u64], returns: i32 },
   tstwo_zero: { args: [u64, u64], returns: i32 },
   tstwo_comm_unique_id: { args: [P], returns: i32 },
@@ -131,6 +132,19 @@ export class DeviceBuffer {
     return out;
   }
   free(): void { check(hip.tstwo_free(this.dev)); }
+}
+
+/** Several small device buffers in ONE round trip (tstwo_download_many): pieces = [device address, words]. */
+export function downloadMany(pieces: readonly (readonly [bigint, number])[]): Uint32Array[] {
+  const srcs = new BigUint64Array(pieces.map(([dev]) => dev));
+  const sizes = new BigUint64Array(pieces.map(([, words]) => BigInt(4 * words)));
+  const total = pieces.reduce((acc, [, words]) => acc + words, 0);
+  const out = new Uint32Array(total);
+  if (total) check(hip.tstwo_download_many(ptr(srcs), ptr(sizes), BigInt(pieces.length), ptr(out)));
+  const res: Uint32Array[] = [];
+  let off = 0;
+  for (const [, words] of pieces) { res.push(out.subarray(off, off + words)); off += words; }
+  return res;
 }
 
 export const ptrs = (devs: bigint[]): BigUint64Array => BigUint64Array.from(devs.length ? devs : [0n]);

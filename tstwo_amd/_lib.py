@@ -64,6 +64,7 @@ _SIGS = {
     "tstwo_set_alloc_mode": [C.c_int],
     "tstwo_upload": [vp, vp, C.c_size_t],
     "tstwo_download": [vp, vp, C.c_size_t],
+    "tstwo_download_many": [C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, vp],
     "tstwo_copy": [vp, vp, C.c_size_t],
     "tstwo_zero": [vp, C.c_size_t],
     "tstwo_graph_begin_capture": [],
@@ -136,7 +137,7 @@ _SIGS = {
 }
 ALLOC_POOL, ALLOC_DIRECT, ALLOC_ASYNC, ALLOC_POISON = 0, 1, 2, 0x10
 # c_void_p arguments above are DEVICE addresses, except these (host memory of any element type)
-HOST_VOID_ARGS = {"tstwo_upload": {1}, "tstwo_download": {0}}
+HOST_VOID_ARGS = {"tstwo_upload": {1}, "tstwo_download": {0}, "tstwo_download_many": {3}}
 # every symbol include/tstwo_hip.h declares (tests check the library exports all of them)
 EXPORTS = sorted(list(_SIGS) + ["tstwo_last_error", "tstwo_version", "tstwo_merkle_layers_bytes"])
 
@@ -260,6 +261,23 @@ class DeviceBuffer:
 
     def zero(self) -> None:
         call("tstwo_zero", vp(self.ptr), self.nbytes)
+
+
+def download_many(pieces) -> list:
+    """Several small device buffers in one round trip (tstwo_download_many): pieces = [(device pointer, n_words)];
+    returns one uint32 array per piece."""
+    n = len(pieces)
+    if n == 0:
+        return []
+    srcs = (vp * n)(*[vp(int(p)) for p, _ in pieces])
+    sizes = (C.c_size_t * n)(*[4 * int(w) for _, w in pieces])
+    out = np.empty(sum(int(w) for _, w in pieces), dtype=np.uint32)
+    call("tstwo_download_many", srcs, sizes, n, out.ctypes.data_as(vp))
+    res, off = [], 0
+    for _, w in pieces:
+        res.append(out[off:off + int(w)])
+        off += int(w)
+    return res
 
 
 def ptr_array(ptrs) -> C.Array:

@@ -141,7 +141,11 @@ class SecureColumnByCoords:
         rows = out.reshape(4, k).T.tolist()
         return [QM31.from_u32_unchecked(*r) for r in rows]
 
-    def to_numpy(self): return [c.to_numpy() for c in self.columns]
+    def to_numpy(self):
+        # the four coordinate columns in one round trip (tstwo_download_many; large columns are fetched one by one inside it)
+        if all(isinstance(c, HipColumn) for c in self.columns) and self.columns[0]._len:
+            return L.download_many([(c.buf.ptr, c._len) for c in self.columns])
+        return [c.to_numpy() for c in self.columns]
     def to_vec(self): return [QM31.from_u32_unchecked(*map(int, t)) for t in zip(*self.to_numpy())]
     toCpu = to_vec
     def ptrs(self): return L.p4([c.ptr for c in self.columns])

@@ -127,8 +127,10 @@ class DeviceChannel:
         from . import _lib as L
         L.call("tstwo_channel_mix_root_draw_felt", C.c_void_p(self.buf.ptr), C.c_void_p(root_ptr or 0), C.c_void_p(felt_ptr or 0))
 
-    def sync_to_host(self) -> Blake2sChannel:
-        st = self.buf.download(count=10)
+    def sync_to_host(self, st=None) -> Blake2sChannel:
+        """The host channel continues from the device state (st: the 10 state words when the caller already fetched them)."""
+        if st is None:
+            st = self.buf.download(count=10)
         self.host._digest = st[:8].astype("<u4").tobytes()
         self.host.n_challenges, self.host.n_sent = int(st[8]), int(st[9])
         return self.host

@@ -27,12 +27,15 @@ struct Context {
     u32 **coltab = nullptr;           // device: 2 pointer tables of coltab_cap entries each (fill_col_table)
     size_t coltab_cap = 0;
     void *pinned = nullptr;           // page-locked host staging for small read-backs (kPinnedBytes)
+    void *result_host = nullptr;      // page-locked host memory mapped into the device (kResultBytes): kernels write small results
+    void *result_dev = nullptr;       // straight into it (tstwo_download_many: one synchronisation, no copy); nullptr: not available
     void *up_ring = nullptr;          // page-locked ring of kUpSlots upload slots (small_h2d: asynchronous uploads)
     hipEvent_t up_done[16] = {};      // recorded behind the copy that last used the slot
     bool up_busy[16] = {};
     int up_next = 0;
 };
 constexpr size_t kPinnedBytes = 64 * 1024;
+constexpr size_t kResultBytes = 256 * 1024;
 constexpr int kUpSlots = 16;
 constexpr size_t kUpSlotBytes = 16 * 1024;
 

@@ -298,6 +298,16 @@ int tstwo_init(int device) {
         }
     }
     if (hipHostMalloc(&c.pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; (void)hipGetLastError(); }
+    {   // result page for tstwo_download_many (same mechanism as the flag)
+        void *h = nullptr, *d = nullptr;
+        if (!getenv("TSTWO_DEVICE_FLAG") && hipHostMalloc(&h, kResultBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+            c.result_host = h;
+            c.result_dev = d;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+        }
+    }
     if (hipHostMalloc(&c.up_ring, kUpSlots * kUpSlotBytes, hipHostMallocDefault) != hipSuccess) { c.up_ring = nullptr; (void)hipGetLastError(); }
     if (c.up_ring)
         for (int k = 0; k < kUpSlots; k++) TSTWO_HIP(hipEventCreateWithFlags(&c.up_done[k], hipEventDisableTiming));
@@ -320,6 +330,8 @@ int tstwo_shutdown(void) {
     if (c.gen_win) (void)hipFree(c.gen_win);
     if (c.flag_host) (void)hipHostFree(c.flag_host);
     else if (c.flag) (void)hipFree(c.flag);
+    if (c.result_host) (void)hipHostFree(c.result_host);
+    c.result_host = c.result_dev = nullptr;
     if (c.pinned) (void)hipHostFree(c.pinned);
     if (c.up_ring) {
         for (int k = 0; k < kUpSlots; k++) (void)hipEventDestroy(c.up_done[k]);
@@ -496,6 +508,59 @@ int tstwo_download(void *host_dst, const void *dev_src, size_t bytes) {
     if (bytes <= kPinnedBytes) return small_d2h(host_dst, dev_src, bytes);
     TSTWO_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    return TSTWO_OK;
+}
+// Several small device buffers in ONE round trip.  A read-back costs a synchronisation whatever its size (~10 us; 25 us with a
+// copy behind it), so six 40-byte .. 4 KiB pieces fetched one by one — the end of a FRI commit: channel state, the last layer's
+// four coordinate columns, a twiddle slice — cost more than the layer kernels in front of them.  One launch packs up to 16
+// pieces (pointers by value in the kernel arguments: no upload) into the mapped result page; then one stream synchronisation.
+namespace {
+struct Pieces { const u32 *src[16]; u32 off[16]; u32 words[16]; };
+__global__ void __launch_bounds__(256) k_pack_pieces(Pieces p, u32 *dst) {
+    const u32 k = blockIdx.y, n = p.words[k];
+    const u32 *__restrict__ s = p.src[k];
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) gstore1(dst, p.off[k] + i, gload1(s, i));
+}
+}  // namespace
+int tstwo_download_many(const void *const *srcs, const size_t *n_bytes, size_t n_pieces, void *host_out) {
+    TSTWO_REQUIRE_READY();
+    if (n_pieces == 0) return TSTWO_OK;
+    if (!srcs || !n_bytes || !host_out) return set_error(TSTWO_ERR_BAD_ARG, "download_many: null argument");
+    size_t total = 0;
+    for (size_t i = 0; i < n_pieces; i++) {
+        if (n_bytes[i] % 4 || (n_bytes[i] && (!srcs[i] || ((uintptr_t)srcs[i] & 3))))
+            return set_error(TSTWO_ERR_BAD_ARG, "download_many: pieces are whole, 4-byte aligned words");
+        total += n_bytes[i];
+    }
+    if (total == 0) return TSTWO_OK;
+    Context &c = g_ctx;
+    if (!c.result_dev || total > kResultBytes) {          // large or no mapped page: piece by piece
+        size_t off = 0;
+        for (size_t i = 0; i < n_pieces; i++) {
+            int rc = tstwo_download((unsigned char *)host_out + off, srcs[i], n_bytes[i]);
+            if (rc) return rc;
+            off += n_bytes[i];
+        }
+        return TSTWO_OK;
+    }
+    size_t off_words = 0;
+    for (size_t i0 = 0; i0 < n_pieces; i0 += 16) {
+        Pieces p = {};
+        u32 k = 0, longest = 0;
+        for (size_t i = i0; i < n_pieces && i < i0 + 16; i++) {
+            if (!n_bytes[i]) continue;
+            p.src[k] = (const u32 *)srcs[i];
+            p.off[k] = (u32)off_words;
+            p.words[k] = (u32)(n_bytes[i] / 4);
+            off_words += n_bytes[i] / 4;
+            longest = p.words[k] > longest ? p.words[k] : longest;
+            k++;
+        }
+        if (k) hipLaunchKernelGGL(k_pack_pieces, dim3((unsigned)ceil_div((size_t)longest, (size_t)256), k), dim3(256), 0, c.stream, p, (u32 *)c.result_dev);
+    }
+    TSTWO_LAUNCH_CHECK();
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    memcpy(host_out, c.result_host, total);
     return TSTWO_OK;
 }
 int tstwo_copy(void *dev_dst, const void *dev_src, size_t bytes) {

@@ -46,7 +46,12 @@ class FriConfig:
         channel.mix_u64(self.log_last_layer_degree_bound)
 
 
-def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = None) -> list:
+def _line_interpolate_uses_tree(evaluation: LineEvaluation, twiddles) -> bool:
+    n = evaluation.len()
+    return twiddles is not None and n >= 2 and evaluation.domain().coset().is_doubling_of(twiddles.rootCoset)
+
+
+def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = None, prefetched=None) -> list:
     """LineEvaluation.interpolate + lineIfft (poly/line.ts:312-390) on the host: the last FRI layer has at most
     2^(log_last_layer_degree_bound + log_blowup_factor) elements.  Returns bit-reversed-order coefficients.
     Vectorised over the layer with numpy u64 (4 coordinate rows; M31 ops are coordinate-wise because every twiddle is
@@ -58,12 +63,18 @@ def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = 
     n = evaluation.len()
     log_n = n.bit_length() - 1
     br = np.array([bit_reverse_index(i, log_n) for i in range(n)], dtype=np.int64)
-    vals = np.stack([c.astype(np.uint64) for c in evaluation.values.to_numpy()])[:, br]       # (4, n), natural order
+    # prefetched = (the 4 coordinate columns, the last n entries of the inverse twiddle tree or None): the caller fetched them
+    # together with other small results in one round trip (FriProver.commit)
+    cols_host = prefetched[0] if prefetched is not None else evaluation.values.to_numpy()
+    vals = np.stack([c.astype(np.uint64) for c in cols_host])[:, br]                          # (4, n), natural order
     domain = evaluation.domain()
     tail = None
-    if twiddles is not None and log_n >= 1 and domain.coset().is_doubling_of(twiddles.rootCoset):
-        L_ = twiddles.itwiddles.len()
-        tail = twiddles.itwiddles.buf.download(count=n, offset=4 * (L_ - n))                  # last n entries of the tree
+    if _line_interpolate_uses_tree(evaluation, twiddles):
+        if prefetched is not None:
+            tail = prefetched[1]
+        else:
+            L_ = twiddles.itwiddles.len()
+            tail = twiddles.itwiddles.buf.download(count=n, offset=4 * (L_ - n))              # last n entries of the tree
     while domain.size() > 1:
         size, half = domain.size(), domain.size() // 2
         k = domain.logSize()
@@ -315,10 +326,23 @@ class FriProver:
                 first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _DeviceTranscript(dch, alphas))
             else:
                 first_layer, inner, layer_eval = FriProver._commit_layers_in_library(config, columns, twiddles, dch, alphas)
-            dch.sync_to_host()                                               # the host channel continues from the device state
+            # what the host needs to finish — the channel state, the last layer's four coordinate columns and the x^-1 slice of
+            # the twiddle tree its interpolation uses — in ONE round trip (six separate read-backs were 0.17 ms of a 0.76 ms commit)
+            n_last = layer_eval.len()
+            pieces = [(dch.buf.ptr, 10)] + [(c.buf.ptr, n_last) for c in layer_eval.values.columns]
+            uses_tree = _line_interpolate_uses_tree(layer_eval, twiddles)
+            if uses_tree:
+                pieces.append((twiddles.itwiddles.buf.ptr + 4 * (twiddles.itwiddles.len() - n_last), n_last))
+            if os.environ.get("TSTWO_FRI_SEPARATE_READBACKS"):               # A/B timing: one tstwo_download per piece
+                got = [L.download_many([pc])[0] for pc in pieces]
+            else:
+                got = L.download_many(pieces)
+            dch.sync_to_host(got[0])                                         # the host channel continues from the device state
+            prefetched = (got[1:5], got[5] if uses_tree else None)
         else:
             first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _HostTranscript(channel))
-        last = FriProver._commit_last_layer(channel, config, layer_eval, twiddles)
+            prefetched = None
+        last = FriProver._commit_last_layer(channel, config, layer_eval, twiddles, prefetched)
         return FriProver(config, first_layer, inner, last)
 
     @staticmethod
@@ -388,11 +412,11 @@ class FriProver:
         return first_layer, inner, layer_eval
 
     @staticmethod
-    def _commit_last_layer(channel, config: FriConfig, layer_eval: LineEvaluation, twiddles: TwiddleTree) -> LinePoly:
+    def _commit_last_layer(channel, config: FriConfig, layer_eval: LineEvaluation, twiddles: TwiddleTree, prefetched=None) -> LinePoly:
         """commitLastLayer (fri.ts:718-754)."""
         if layer_eval.len() != config.last_layer_domain_size():
             raise ValueError("last layer domain size mismatch")
-        coeffs_br = line_interpolate(layer_eval, twiddles)
+        coeffs_br = line_interpolate(layer_eval, twiddles, prefetched)
         log_n = len(coeffs_br).bit_length() - 1
         ordered = [coeffs_br[bit_reverse_index(i, log_n)] for i in range(len(coeffs_br))]   # intoOrderedCoefficients
         bound = 1 << config.log_last_layer_degree_bound
