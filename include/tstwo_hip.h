@@ -180,6 +180,12 @@ int tstwo_eval_at_point_batch(const uint32_t *const *coeffs, size_t n_cols, uint
  * tree's root), out = 2^(log_n-1) rows.  log_n == 0 -> TSTWO_ERR_TOO_SMALL. */
 int tstwo_fri_fold_line(const uint32_t *const in[4], uint32_t log_n, const uint32_t *itw, uint32_t tw_log,
                         const uint32_t alpha[4], uint32_t *const out[4]);
+/* LineEvaluation.interpolate (poly/line.ts:312-329: bit reversal, lineIfft :354-390, scaling by 1/n) of an evaluation of
+ * 2^log_n <= 2^12 rows on LineDomain(coset of log log_n, a doubling of the tree's root): in = the evaluation's four coordinate
+ * columns as LineEvaluation stores them (bit-reversed order), out = the LinePoly coefficients in the reference's bit-reversed
+ * order, per coordinate.  The last FRI layer (fri.ts:718-754) is the caller.  Asynchronous. */
+int tstwo_line_interpolate(const uint32_t *const in[4], uint32_t log_n, const uint32_t *itw, uint32_t tw_log,
+                           uint32_t *const out[4]);
 /* fold_circle_into_line (fri.ts:162-192): src = 2^log_n rows on a CircleDomain whose half coset is a
  * doubling of the tree's root; dst (dst_len rows) is updated in place: dst*alpha^2 + (alpha*f1 + f0).
  * dst_len != 2^(log_n-1) -> TSTWO_ERR_LEN_MISMATCH. */

@@ -811,6 +811,67 @@ def test_line_interpolate_with_and_without_tree():
     assert [x.tup() for x in a] == [x.tup() for x in b]
 
 
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 7, 9, 12])
+def test_line_interpolate_on_device_equals_reference_formulation(k):
+    """tstwo_line_interpolate (one workgroup, x^-1 from the tree) == LineEvaluation.interpolate as the reference computes it
+    (per-element domain.at(i).inverse(), poly/line.ts:312-390), and evaluating the resulting LinePoly at domain points gives the
+    evaluation back (the property of poly/line.test.ts)."""
+    from tstwo_amd.fri_prover import line_interpolate_device, line_interpolate_words
+    root = T.Coset.half_odds(13)
+    tw = T.precompute_twiddles(root)
+    coset = root.repeated_double(13 - k)
+    cols = [rand_column(7100 + 10 * k + c, 1 << k) for c in range(4)]
+    ev = T.LineEvaluation(T.LineDomain(coset), T.SecureColumnByCoords.from_numpy(cols))
+    buf = line_interpolate_device(ev, tw)
+    assert buf is not None
+    got = buf.download(count=4 << k).reshape(4, 1 << k)
+    want = line_interpolate_words(ev, None)                       # the reference's per-element inverses
+    assert np.array_equal(got, want)
+    if 1 <= k <= 7:
+        poly = T.LinePoly([T.QM31.from_u32_unchecked(*row) for row in got.T.tolist()])
+        from tstwo_amd.circle import bit_reverse_index
+        for i in (0, 1, (1 << k) - 1):
+            x = T.QM31.from_(ev.domain().at(bit_reverse_index(i, k)))
+            assert poly.eval_at_point(x).tup() == tuple(int(c[i]) for c in cols)
+
+
+def test_line_interpolate_capi_errors():
+    tw = T.precompute_twiddles(T.Coset.half_odds(6))
+    cols = T.SecureColumnByCoords.from_numpy([rand_column(7300 + c, 1 << 13) for c in range(4)])
+    out = L.DeviceBuffer(16 << 13)
+    o4 = L.p4([out.ptr + (4 << 13) * c for c in range(4)])
+    with pytest.raises(L.TstwoError, match="at most 2\\^12 values"):
+        L.call("tstwo_line_interpolate", cols.ptrs(), 13, L.vp(tw.itwiddles.buf.ptr), tw.log_size, o4)
+    with pytest.raises(L.TstwoError, match="Not enough twiddles!"):
+        L.call("tstwo_line_interpolate", cols.ptrs(), 8, L.vp(tw.itwiddles.buf.ptr), tw.log_size, o4)
+    with pytest.raises(L.TstwoError, match="null"):
+        L.call("tstwo_line_interpolate", cols.ptrs(), 4, L.vp(0), tw.log_size, o4)
+
+
+def test_fri_commit_device_last_layer_equals_host_last_layer(monkeypatch):
+    """The last layer interpolated on the device (one read-back with the channel state) and on the host (TSTWO_FRI_HOST_LAST_LAYER,
+    and the per-piece read-backs of TSTWO_FRI_SEPARATE_READBACKS) give the same last-layer polynomial and channel."""
+    LOGD, BLOW = 9, 2
+    domain = T.CanonicCoset(LOGD + BLOW).circleDomain()
+    tw = T.precompute_twiddles(domain.halfCoset)
+    polys = [T.HipCirclePoly(rand_column(7400 + c, 1 << LOGD)) for c in range(4)]
+    evs = T.evaluate_polynomials(polys, domain, tw)
+    col = T.SecureEvaluation(domain, T.SecureColumnByCoords([e.values for e in evs]))
+    results = []
+    for env in (None, "TSTWO_FRI_HOST_LAST_LAYER", "TSTWO_FRI_SEPARATE_READBACKS"):
+        for bound in (0, 3, 5):
+            if env:
+                monkeypatch.setenv(env, "1")
+            ch = T.Blake2sChannel()
+            fp = T.FriProver.commit(ch, T.FriConfig(bound, BLOW, 10), [col], tw)
+            if env:
+                monkeypatch.delenv(env)
+            results.append((env, bound, [c.tup() for c in fp.last_layer_poly.coeffs], ch.digest_bytes() if hasattr(ch, "digest_bytes") else ch._digest))
+    base = {b: r for e, b, *r in results if e is None}
+    for e, b, *r in results:
+        assert r == base[b], (e, b)
+
+
 # ---------------------------------------------------------------- poly/circle/secure_poly.ts, poly.ts:56-73, poly/utils.ts:78-100
 def test_secure_circle_poly_roundtrip_and_eval():
     LOG = 7

@@ -63,6 +63,7 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_poly_extend: { args: [u64, u32, u64, u32], returns: i32 },
   tstwo_eval_at_point: { args: [u64, u32, P, P, P], returns: i32 },
   tstwo_eval_at_point_batch: { args: [P, u64, u32, P, P, P], returns: i32 },
+  tstwo_line_interpolate: { args: [P, u32, u64, u32, P], returns: i32 },
   tstwo_fri_fold_line: { args: [P, u32, u64, u32, P, P], returns: i32 },
   tstwo_fri_fold_line_tw: { args: [P, u32, u64, P, P], returns: i32 },
   tstwo_fri_fold_circle_into_line: { args: [P, u64, P, u32, u64, u32, P], returns: i32 },

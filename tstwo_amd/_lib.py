@@ -105,6 +105,7 @@ _SIGS = {
     "tstwo_poly_extend": [vp, C.c_uint32, vp, C.c_uint32],
     "tstwo_eval_at_point": [vp, C.c_uint32, u32p, u32p, u32p],
     "tstwo_eval_at_point_batch": [C.POINTER(vp), C.c_size_t, C.c_uint32, u32p, u32p, u32p],
+    "tstwo_line_interpolate": [P4, C.c_uint32, vp, C.c_uint32, P4],
     "tstwo_fri_fold_line": [P4, C.c_uint32, vp, C.c_uint32, u32p, P4],
     "tstwo_fri_fold_circle_into_line": [P4, C.c_size_t, P4, C.c_uint32, vp, C.c_uint32, u32p],
     "tstwo_fri_fold_line_tw": [P4, C.c_uint32, vp, u32p, P4],

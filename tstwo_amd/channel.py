@@ -48,11 +48,15 @@ class Blake2sChannel:
     def mix_root(self, root: bytes) -> None:       # Blake2sMerkleChannel.mix_root (vcs/blake2_merkle.ts:28-31)
         self._update_digest(hashlib.blake2s(self._digest + root).digest())
 
-    def mix_felts(self, felts) -> None:            # blake2.ts:113-118 (QM31.into_slice: 4 LE u32 each)
+    def mix_felts(self, felts, _le_bytes: bytes | None = None) -> None:            # blake2.ts:113-118 (QM31.into_slice: 4 LE u32 each)
         h = hashlib.blake2s(self._digest)
-        for f in felts:
-            for v in f.tup():
-                h.update(int(v).to_bytes(4, "little"))
+        if _le_bytes is not None:                  # the caller already holds the felts' into_slice bytes (16 per felt)
+            assert len(_le_bytes) == 16 * len(felts)
+            h.update(_le_bytes)
+        else:
+            for f in felts:
+                for v in f.tup():
+                    h.update(int(v).to_bytes(4, "little"))
         self._update_digest(h.digest())
 
     def mix_u32s(self, data) -> None:              # blake2.ts:120-136

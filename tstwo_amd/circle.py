@@ -254,3 +254,20 @@ def bit_reverse_index(i: int, log_size: int) -> int:
         r = (r << 1) | (i & 1)
         i >>= 1
     return r
+
+
+import functools  # noqa: E402
+
+
+@functools.lru_cache(maxsize=64)
+def bit_reverse_perm(log_size: int):
+    """[bit_reverse_index(i, log_size) for i < 2^log_size] as a read-only int64 array (cached: the host side of a FRI proof asks
+    for the same few sizes again and again)."""
+    import numpy as np
+    idx = np.arange(1 << log_size, dtype=np.int64)
+    r = np.zeros_like(idx)
+    for _ in range(log_size):
+        r = (r << 1) | (idx & 1)
+        idx >>= 1
+    r.setflags(write=False)
+    return r

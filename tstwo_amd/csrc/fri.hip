@@ -73,6 +73,37 @@ __global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t
 // measured in round 3: fold_circle_into_line log 24 103.9 against 106.7 us, fold_line log 23 37.9 against 35.3 us: the
 // folds already move 5.0 - 5.9 TB/s and the 120 VGPRs of the 4-row form cost as much occupancy as the wider accesses
 // gain.  Removed; gpurun_out/r03b/f1.log.)
+// LineEvaluation.interpolate (poly/line.ts:312-329) with lineIfft (line.ts:354-390) for a layer that fits one workgroup's LDS — the
+// last FRI layer (2^7 rows by default): bit reversal on the way in, log_n levels of ibutterflies with x^-1 =
+// domain.at(i)^-1 taken from the inverse twiddle tree (level of coset size 2^k: itw_end - 2^k + bitrev(i, k - 1)), the 1/n
+// scaling, coefficients out in the reference's bit-reversed order.  One workgroup, coordinate c of a value handled like a
+// column (every twiddle is in the base field).
+__global__ void __launch_bounds__(256) k_line_interpolate(CSoa4 in, Soa4 out, u32 log_n, const u32 *__restrict__ itw_end, u32 n_inv) {
+    extern __shared__ u32 lsh[];                 // [4][n]
+    const u32 n = 1u << log_n, t = threadIdx.x;
+    for (u32 i = t; i < 4 * n; i += 256) {
+        const u32 c = i >> log_n, j = i & (n - 1);
+        const u32 nat = log_n ? __brev(j) >> (32 - log_n) : 0u;
+        lsh[(c << log_n) + nat] = gload1(in.p[c] + j);
+    }
+    __syncthreads();
+    for (u32 k = log_n; k >= 1; k--) {                              // chunks of 2^k values
+        const u32 half = 1u << (k - 1);
+        for (u32 w = t; w < 2 * n; w += 256) {                      // 4 coordinates x n/2 butterflies
+            const u32 c = w >> (log_n - 1), b = w & ((n >> 1) - 1);
+            const u32 i = b & (half - 1), chunk = b >> (k - 1);
+            const u32 l = (c << log_n) + (chunk << k) + i, r = l + half;
+            const u32 br = k > 1 ? __brev(i) >> (32 - (k - 1)) : 0u;
+            const u32 x_inv = itw_end[(int)br - (int)(1u << k)];
+            const u32 a = lsh[l], bb = lsh[r];
+            lsh[l] = m31_add(a, bb);                                  // ibutterfly (fft.ts:25-30)
+            lsh[r] = m31_mul(m31_sub(a, bb), x_inv);
+        }
+        __syncthreads();
+    }
+    for (u32 i = t; i < 4 * n; i += 256) gstore1(out.p[i >> log_n] + (i & (n - 1)), m31_mul(lsh[i], n_inv));
+}
+
 // backend/cpu/fri.ts:97-123: sums of the two halves of each coordinate column (exact in u64).
 __global__ void __launch_bounds__(256) k_half_sums(CSoa4 in, size_t n, unsigned long long *sums /* [4][2] */) {
     __shared__ unsigned long long sh[256 / 64];
@@ -278,6 +309,20 @@ int tstwo_fri_fold_line_tw(const u32 *const in[4], u32 log_n, const u32 *inv_x, 
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
     launch_fold_line(i4, o4, n_out, inv_x, to_q(alpha), nullptr);
+    TSTWO_LAUNCH_CHECK();
+    return TSTWO_OK;
+}
+
+int tstwo_line_interpolate(const u32 *const in[4], u32 log_n, const u32 *itw, u32 tw_log, u32 *const out[4]) {
+    TSTWO_REQUIRE_READY();
+    TSTWO_REQUIRE_TABLE(in, 4); TSTWO_REQUIRE_TABLE(out, 4);
+    if (!itw) return set_error(TSTWO_ERR_BAD_ARG, "null device pointer");
+    if (log_n > 12) return set_error(TSTWO_ERR_BAD_ARG, "line_interpolate: at most 2^12 values (one workgroup); larger layers are interpolated by the caller");
+    if (tw_log > 31 || log_n > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+    CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
+    Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    const u32 n_inv = host::inv((u32)1 << log_n);
+    hipLaunchKernelGGL(k_line_interpolate, dim3(1), dim3(256), (size_t)16 << log_n, ctx().stream, i4, o4, log_n, itw + ((size_t)1 << tw_log), n_inv);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }

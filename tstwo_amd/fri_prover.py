@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 from . import _lib as L
 from .backend import HipColumn, SecureColumnByCoords
 from .channel import DeviceChannel
-from .circle import Coset, LineDomain, bit_reverse_index
+from .circle import Coset, LineDomain, bit_reverse_index, bit_reverse_perm
 from .queries import Queries, get_query_positions_by_log_size
 from .fields import M31, P, QM31
 from .fri import CIRCLE_TO_LINE_FOLD_STEP, HipFriOps
@@ -52,8 +52,29 @@ def _line_interpolate_uses_tree(evaluation: LineEvaluation, twiddles) -> bool:
 
 
 def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = None, prefetched=None) -> list:
+    """LineEvaluation.interpolate (poly/line.ts:312-329): the LinePoly coefficients, bit-reversed order, as QM31."""
+    vals = line_interpolate_words(evaluation, twiddles, prefetched)
+    return [QM31.from_u32_unchecked(*row) for row in vals.T.tolist()]
+
+
+def line_interpolate_device(evaluation: LineEvaluation, twiddles: TwiddleTree) -> "L.DeviceBuffer | None":
+    """The same on the device (tstwo_line_interpolate: one workgroup, at most 2^12 values on a doubling of the twiddle tree's
+    root): enqueues the kernel and returns the buffer of the four coefficient columns (4 x n words, coordinate-major) for the
+    caller to fetch together with whatever else it reads back; None when the layer does not qualify."""
+    n = evaluation.len()
+    if twiddles is None or n > (1 << 12) or not all(isinstance(c, HipColumn) for c in evaluation.values.columns):
+        return None
+    if n >= 2 and not _line_interpolate_uses_tree(evaluation, twiddles):
+        return None
+    out = L.DeviceBuffer(16 * n)
+    L.call("tstwo_line_interpolate", evaluation.values.ptrs(), n.bit_length() - 1, L.vp(twiddles.itwiddles.buf.ptr),
+           twiddles.log_size, L.p4([out.ptr + 4 * n * k for k in range(4)]))
+    return out
+
+
+def line_interpolate_words(evaluation: LineEvaluation, twiddles: TwiddleTree | None = None, prefetched=None):
     """LineEvaluation.interpolate + lineIfft (poly/line.ts:312-390) on the host: the last FRI layer has at most
-    2^(log_last_layer_degree_bound + log_blowup_factor) elements.  Returns bit-reversed-order coefficients.
+    2^(log_last_layer_degree_bound + log_blowup_factor) elements.  Returns the bit-reversed-order coefficients as a (4, n) uint32 array.
     Vectorised over the layer with numpy u64 (4 coordinate rows; M31 ops are coordinate-wise because every twiddle is
     in the base field).  The x^-1 of each level are read from the tail of the inverse twiddle tree when the domain is a
     doubling of its root (level of log size k = 2^(k-1) entries, bit-reversed); otherwise they are computed per element
@@ -62,7 +83,7 @@ def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = 
     P_ = np.uint64(P)
     n = evaluation.len()
     log_n = n.bit_length() - 1
-    br = np.array([bit_reverse_index(i, log_n) for i in range(n)], dtype=np.int64)
+    br = bit_reverse_perm(log_n)
     # prefetched = (the 4 coordinate columns, the last n entries of the inverse twiddle tree or None): the caller fetched them
     # together with other small results in one round trip (FriProver.commit)
     cols_host = prefetched[0] if prefetched is not None else evaluation.values.to_numpy()
@@ -80,7 +101,7 @@ def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = 
         k = domain.logSize()
         if tail is not None:
             seg = tail[n - size:n - half]                                                     # tree[L - 2^k : L - 2^(k-1)]
-            inv = seg[[bit_reverse_index(i, k - 1) for i in range(half)]].astype(np.uint64)
+            inv = seg[bit_reverse_perm(k - 1)].astype(np.uint64)
         else:
             inv = np.array([domain.at(i).inverse().value for i in range(half)], dtype=np.uint64)
         v = vals.reshape(4, n // size, 2, half)
@@ -89,8 +110,7 @@ def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = 
         vals = np.stack([s_, d_], axis=2).reshape(4, n)
         domain = domain.double()
     len_inv = np.uint64(M31.from_(n).inverse().value)
-    vals = vals * len_inv % P_
-    return [QM31.from_u32_unchecked(*(int(vals[c, i]) for c in range(4))) for i in range(n)]
+    return (vals * len_inv % P_).astype(np.uint32)                                             # (4, n) coefficient words
 
 
 class LinePoly:
@@ -326,19 +346,26 @@ class FriProver:
                 first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _DeviceTranscript(dch, alphas))
             else:
                 first_layer, inner, layer_eval = FriProver._commit_layers_in_library(config, columns, twiddles, dch, alphas)
-            # what the host needs to finish — the channel state, the last layer's four coordinate columns and the x^-1 slice of
-            # the twiddle tree its interpolation uses — in ONE round trip (six separate read-backs were 0.17 ms of a 0.76 ms commit)
+            # what the host needs to finish — the channel state and the last layer's polynomial — in ONE round trip (six separate
+            # read-backs were 0.17 ms of a 0.76 ms commit).  The interpolation itself (LineEvaluation.interpolate) runs on the
+            # device when the layer fits one workgroup; otherwise its inputs (coordinate columns, x^-1 slice of the tree) come back.
             n_last = layer_eval.len()
-            pieces = [(dch.buf.ptr, 10)] + [(c.buf.ptr, n_last) for c in layer_eval.values.columns]
+            separate = bool(os.environ.get("TSTWO_FRI_SEPARATE_READBACKS"))   # A/B timing: round 3's first form, one tstwo_download per piece
+            coeff_buf = None if separate or os.environ.get("TSTWO_FRI_HOST_LAST_LAYER") else line_interpolate_device(layer_eval, twiddles)
+            pieces = [(dch.buf.ptr, 10)]
             uses_tree = _line_interpolate_uses_tree(layer_eval, twiddles)
-            if uses_tree:
-                pieces.append((twiddles.itwiddles.buf.ptr + 4 * (twiddles.itwiddles.len() - n_last), n_last))
-            if os.environ.get("TSTWO_FRI_SEPARATE_READBACKS"):               # A/B timing: one tstwo_download per piece
-                got = [L.download_many([pc])[0] for pc in pieces]
+            if coeff_buf is not None:
+                pieces.append((coeff_buf.ptr, 4 * n_last))
             else:
-                got = L.download_many(pieces)
+                pieces += [(c.buf.ptr, n_last) for c in layer_eval.values.columns]
+                if uses_tree:
+                    pieces.append((twiddles.itwiddles.buf.ptr + 4 * (twiddles.itwiddles.len() - n_last), n_last))
+            got = [L.download_many([pc])[0] for pc in pieces] if separate else L.download_many(pieces)
             dch.sync_to_host(got[0])                                         # the host channel continues from the device state
-            prefetched = (got[1:5], got[5] if uses_tree else None)
+            if coeff_buf is not None:
+                prefetched = {"coeffs": got[1].reshape(4, n_last)}
+            else:
+                prefetched = (got[1:5], got[5] if uses_tree else None)
         else:
             first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _HostTranscript(channel))
             prefetched = None
@@ -416,14 +443,20 @@ class FriProver:
         """commitLastLayer (fri.ts:718-754)."""
         if layer_eval.len() != config.last_layer_domain_size():
             raise ValueError("last layer domain size mismatch")
-        coeffs_br = line_interpolate(layer_eval, twiddles, prefetched)
-        log_n = len(coeffs_br).bit_length() - 1
-        ordered = [coeffs_br[bit_reverse_index(i, log_n)] for i in range(len(coeffs_br))]   # intoOrderedCoefficients
+        import numpy as np
+        if isinstance(prefetched, dict):
+            cw = prefetched["coeffs"]                                        # interpolated on the device (line_interpolate_device)
+        else:
+            cw = line_interpolate_words(layer_eval, twiddles, prefetched)    # (4, n) words, bit-reversed coefficient order
+        log_n = cw.shape[1].bit_length() - 1
+        ordered = cw[:, bit_reverse_perm(log_n)]                             # intoOrderedCoefficients
         bound = 1 << config.log_last_layer_degree_bound
-        if any(c.tup() != (0, 0, 0, 0) for c in ordered[bound:]):
+        if ordered[:, bound:].any():
             raise ValueError("invalid degree")
-        last = LinePoly.from_ordered_coefficients(ordered[:bound])
-        channel.mix_felts(last.coeffs)          # Rust: channel.mix_felts(&last_layer_poly) = its bit-reversed coefficient slice
+        # LinePoly.from_ordered_coefficients(ordered[:bound]): bit-reversed order over the bound
+        words = np.ascontiguousarray(ordered[:, :bound][:, bit_reverse_perm(config.log_last_layer_degree_bound)].T, dtype="<u4")
+        last = LinePoly([QM31.from_u32_unchecked(*row) for row in words.tolist()])
+        channel.mix_felts(last.coeffs, _le_bytes=words.tobytes())   # Rust: channel.mix_felts(&last_layer_poly) = its bit-reversed coefficient slice
         return last
 
     def decommit(self, channel) -> tuple:
