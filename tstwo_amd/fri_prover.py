@@ -17,7 +17,7 @@ from .queries import Queries, get_query_positions_by_log_size
 from .fields import M31, P, QM31
 from .fri import CIRCLE_TO_LINE_FOLD_STEP, HipFriOps
 from .poly import LineEvaluation, SecureEvaluation, TwiddleTree
-from .vcs import DeviceHashLayer, MerkleDecommitment, MerkleProver
+from .vcs import DeviceHashLayer, HashSlices, M31Values, MerkleDecommitment, MerkleProver
 
 FOLD_STEP = 1
 
@@ -515,7 +515,7 @@ class FriProver:
         proofs, e0, h0, w0 = [], 0, 0, 0
         for r, layer in enumerate(layers):
             ne, nh, nw = counts[3 * r], counts[3 * r + 1], counts[3 * r + 2]
-            dec = MerkleDecommitment([hb[32 * (h0 + i):32 * (h0 + i) + 32] for i in range(nh)], [M31(v) for v in wl[w0:w0 + nw]])
+            dec = MerkleDecommitment(HashSlices(hb[32 * h0:32 * (h0 + nh)], nh), M31Values(wl[w0:w0 + nw]))
             layer.merkle_tree._root = rb[32 * r:32 * r + 32]          # (what root() would read back: 32 bytes per tree)
             proofs.append(FriLayerProof(QM31Rows(ev[e0:e0 + ne]), dec, layer.merkle_tree._root))
             e0, h0, w0 = e0 + ne, h0 + nh, w0 + nw

@@ -48,6 +48,68 @@ class HipMerkleOps:
         return out
 
 
+class _LazyList:
+    """A list whose elements are built when they are looked at.  Sub-classes give `_n()` and `_make(i)`; the first mutation
+    (a test tampering with a proof, a caller appending) turns it into an ordinary list of built elements."""
+    __slots__ = ("_items",)
+
+    def _all(self):
+        if self._items is None:
+            self._items = [self._make(i) for i in range(self._n())]
+        return self._items
+
+    def __len__(self): return self._n() if self._items is None else len(self._items)
+    def __getitem__(self, i):
+        if self._items is not None:
+            return self._items[i]
+        if isinstance(i, slice):
+            return [self._make(k) for k in range(*i.indices(self._n()))]
+        n = self._n()
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("list index out of range")
+        return self._make(i)
+    def __iter__(self): return iter(self._items) if self._items is not None else (self._make(i) for i in range(self._n()))
+    def __setitem__(self, i, v): self._all()[i] = v
+    def append(self, v): self._all().append(v)
+    def pop(self, i=-1): return self._all().pop(i)
+    def __eq__(self, o): return list(self) == list(o)
+    def __add__(self, o): return list(self) + list(o)
+    def __radd__(self, o): return list(o) + list(self)
+    def __repr__(self): return f"{type(self).__name__}({list(self)!r})"
+    def __deepcopy__(self, memo):
+        import copy
+        c = copy.copy(self)
+        if c._items is not None:
+            c._items = list(c._items)
+        return c
+
+
+class M31Values(_LazyList):
+    """M31 over the u32 words that came back from the device (queried values, column witness).  Elements become M31 objects when
+    they are looked at (the verifier, a serialiser), not when the proof is assembled: the 1280 queried values of a 40-query,
+    32-column opening were a quarter of a millisecond of host objects otherwise."""
+    __slots__ = ("words",)
+
+    def __init__(self, words):
+        self.words, self._items = words, None                  # list of ints
+
+    def _n(self): return len(self.words)
+    def _make(self, i): return M31(self.words[i])
+
+
+class HashSlices(_LazyList):
+    """32-byte digests over one bytes object (the hash witness as it came back from the device)."""
+    __slots__ = ("raw", "n")
+
+    def __init__(self, raw: bytes, n: int):
+        self.raw, self.n, self._items = raw, n, None
+
+    def _n(self): return self.n
+    def _make(self, i): return self.raw[32 * i:32 * i + 32]
+
+
 class MerkleProver:
     """MerkleProver.commit / root (vcs/prover.ts:13-30,111-113): layers[0] = [root], all layers retained on device."""
 
@@ -133,9 +195,9 @@ class MerkleProver:
                queried.ctypes.data_as(L.u32p), C.byref(n_q), hashes.ctypes.data_as(L.u8p), C.byref(n_h),
                colwit.ctypes.data_as(L.u32p), C.byref(n_w))
         hb = hashes.tobytes()
-        dec = MerkleDecommitment([hb[32 * i:32 * i + 32] for i in range(n_h.value)], [M31(v) for v in colwit[:n_w.value].tolist()])
-        # (FRI layers already hold their queried evaluations: want_queried=False skips building the M31 list)
-        return ([M31(v) for v in queried[:n_q.value].tolist()] if want_queried else None), dec
+        dec = MerkleDecommitment(HashSlices(hb, n_h.value), M31Values(colwit[:n_w.value].tolist()))
+        # (FRI layers already hold their queried evaluations: want_queried=False skips the queried values)
+        return (M31Values(queried[:n_q.value].tolist()) if want_queried else None), dec
 
     @staticmethod
     def decommit_many(requests, want_queried: bool = True) -> list:
@@ -173,8 +235,8 @@ class MerkleProver:
         ql, wl = queried.tolist() if want_queried else None, colwit[:totals[2]].tolist()
         for r in range(len(requests)):
             nq_, nh_, nw_ = counts[3 * r], counts[3 * r + 1], counts[3 * r + 2]
-            dec = MerkleDecommitment([hb[32 * (h0 + i):32 * (h0 + i) + 32] for i in range(nh_)], [M31(v) for v in wl[w0:w0 + nw_]])
-            out.append(([M31(v) for v in ql[q0:q0 + nq_]] if want_queried else None, dec))
+            dec = MerkleDecommitment(HashSlices(hb[32 * h0:32 * (h0 + nh_)], nh_), M31Values(wl[w0:w0 + nw_]))
+            out.append((M31Values(ql[q0:q0 + nq_]) if want_queried else None, dec))
             q0, h0, w0 = q0 + nq_, h0 + nh_, w0 + nw_
         return out
 
