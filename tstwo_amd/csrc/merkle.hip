@@ -532,6 +532,49 @@ __device__ __forceinline__ void b2s_quad_block64(const u32 (&m)[16], u32 j, u32 
     o_hi = h_hi ^ b ^ d;
 }
 
+// The same with the message in LDS instead of registers: lane j of the quad reads its words of round r — m[SIGMA[r][2j]],
+// m[SIGMA[r][2j+1]] for the column step, m[SIGMA[r][8+2j]], m[SIGMA[r][8+2j+1]] for the diagonal step — from 40 LDS byte addresses
+// it computed ONCE (quad_msg_addrs: the quad's message slot does not move between tree levels).  40 ds_read_b32 per compression
+// instead of 120 v_cndmask (the three selects per word above): a third fewer issue slots on a path where one wave issues alone.
+typedef __attribute__((address_space(3))) const u32 lds_cu32;
+struct QuadMsgAddrs { u32 a[40]; };
+__device__ __forceinline__ void quad_msg_addrs(QuadMsgAddrs &qa, u32 msg_byte_base, u32 j) {
+#define B2SQ_ADDR(r, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                   \
+    qa.a[4 * r + 0] = msg_byte_base + sel4(4u * s0, 4u * s2, 4u * s4, 4u * s6, j);                             \
+    qa.a[4 * r + 1] = msg_byte_base + sel4(4u * s1, 4u * s3, 4u * s5, 4u * s7, j);                             \
+    qa.a[4 * r + 2] = msg_byte_base + sel4(4u * s8, 4u * s10, 4u * s12, 4u * s14, j);                          \
+    qa.a[4 * r + 3] = msg_byte_base + sel4(4u * s9, 4u * s11, 4u * s13, 4u * s15, j);
+    B2SQ_ADDR(0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2SQ_ADDR(1, 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    B2SQ_ADDR(2, 11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    B2SQ_ADDR(3, 7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    B2SQ_ADDR(4, 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    B2SQ_ADDR(5, 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    B2SQ_ADDR(6, 12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    B2SQ_ADDR(7, 13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    B2SQ_ADDR(8, 6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    B2SQ_ADDR(9, 10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+#undef B2SQ_ADDR
+}
+__device__ __forceinline__ u32 lds_word(u32 byte_addr) { return *(lds_cu32 *)(uintptr_t)byte_addr; }
+__device__ __forceinline__ void b2s_quad_block64_lds(const QuadMsgAddrs &qa, u32 j, u32 &o_lo, u32 &o_hi) {
+    const u32 ivlo = sel4(IV0, IV1, IV2, IV3, j), ivhi = sel4(IV4, IV5, IV6, IV7, j);
+    const u32 h_lo = ivlo ^ (j == 0 ? 0x01010020u : 0u), h_hi = ivhi;
+    u32 a = h_lo, b = h_hi, c = ivlo, d = ivhi ^ sel4(64u, 0u, 0xFFFFFFFFu, 0u, j);
+    u32 w[40];
+#pragma unroll
+    for (int k = 0; k < 40; k++) w[k] = lds_word(qa.a[k]);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        B2S_G(a, b, c, d, w[4 * r], w[4 * r + 1]);
+        b = quad_rot(b, 1); c = quad_rot(c, 2); d = quad_rot(d, 3);
+        B2S_G(a, b, c, d, w[4 * r + 2], w[4 * r + 3]);
+        b = quad_rot(b, 3); c = quad_rot(c, 2); d = quad_rot(d, 1);
+    }
+    o_lo = h_lo ^ a ^ c;
+    o_hi = h_hi ^ b ^ d;
+}
+
 // ---- Blake2sChannel on the device (channel/blake2.ts:25-224, Rust semantics).  State = 10 words: digest[8], n_challenges,
 // n_sent.  One quad of lanes runs the (latency-bound) compressions; used by the FRI commit loop so that a layer's root
 // never has to travel to the host before the next fold can be launched.
@@ -582,30 +625,30 @@ __device__ __forceinline__ void chan_mix_draw(u32 (&d)[8], u32 &n_chal, u32 &n_s
 // Levels log_child-1 .. log_child-levels, 4 lanes per node: a workgroup of WG lanes owns WG/4 consecutive parents of the
 // first level and everything above them (WG/4 -> 1 is log2(WG/4)+1 levels).  Children digests live in LDS between levels.
 // the level loop shared by k_merkle_upq and k_merkle_leaf4_upq: `sh` holds the 2*active child digests of this workgroup
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int WG>
-__device__ __forceinline__ void upq_levels(uint4 *__restrict__ layers, u32 *sh, u32 log_child, u32 levels, u32 active) {
+__device__ __forceinline__ void upq_levels(uint4 *__restrict__ layers, u32 *sh, u32 log_child, u32 levels, u32 active, u32 blk) {
     const u32 t = threadIdx.x, q = t >> 2, j = t & 3;
+    QuadMsgAddrs qa;                                               // this lane's 40 message-word addresses: the quad's slot sh[16q..16q+15]
+    quad_msg_addrs(qa, (u32)(uintptr_t)(__attribute__((address_space(3))) u32 *)sh + 64u * q, j);
     for (u32 lv = 1; lv <= levels; lv++) {
         const u32 log_out = log_child - lv;
         u32 o_lo = 0, o_hi = 0;
         const bool on = q < active;                                // quad-uniform
         if (on) {
-            u32 m[16];
-            const uint4 *src = reinterpret_cast<const uint4 *>(sh) + 4 * q;
-            uint4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-            m[0] = c0.x; m[1] = c0.y; m[2] = c0.z; m[3] = c0.w; m[4] = c1.x; m[5] = c1.y; m[6] = c1.z; m[7] = c1.w;
-            m[8] = c2.x; m[9] = c2.y; m[10] = c2.z; m[11] = c2.w; m[12] = c3.x; m[13] = c3.y; m[14] = c3.z; m[15] = c3.w;
-            b2s_quad_block64(m, j, o_lo, o_hi);
-            u32 *out = reinterpret_cast<u32 *>(layers + 2 * (((size_t)1 << log_out) - 1) + 2 * ((size_t)blockIdx.x * active + q));
+            b2s_quad_block64_lds(qa, j, o_lo, o_hi);
+            u32 *out = reinterpret_cast<u32 *>(layers + 2 * (((size_t)1 << log_out) - 1) + 2 * ((size_t)blk * active + q));
             out[j] = o_lo;
             out[4 + j] = o_hi;
         }
-        __syncthreads();                                           // every quad has read its children
+        // LDS-only barriers: __syncthreads() also waits for the digest stores above to be acknowledged by memory (vmcnt(0)) —
+        // nobody in this launch reads them back, and that wait was most of a level's time on this latency-bound path
+        lds_only_barrier();                                        // every quad has read its children
         if (on) {
             sh[8 * q + j] = o_lo;
             sh[8 * q + 4 + j] = o_hi;
         }
-        __syncthreads();
+        lds_only_barrier();
         active >>= 1;
     }
 }
@@ -639,7 +682,7 @@ __global__ void __launch_bounds__(WG) k_merkle_upq(TreeSet ts, u32 log_child, u3
         if (t < 4 * active) reinterpret_cast<uint4 *>(sh)[t] = child[t];      // 2*active digests = 4*active uint4
     }
     __syncthreads();
-    upq_levels<WG>(layers, sh, log_child, levels, active);
+    upq_levels<WG>(layers, sh, log_child, levels, active, blockIdx.x);
     if (log_child == levels) chan_step_from_lds(hk, sh);          // this launch reached layer 0: the root is sh[0..7]
 }
 // A small 4-column tree (every FRI layer below 2^17 rows) without a launch of its own for the leaves: the first 2*active lanes
@@ -672,7 +715,7 @@ __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(u32 *__restrict__ c0, u
         reinterpret_cast<uint4 *>(sh)[2 * t + 1] = hi;
     }
     __syncthreads();
-    upq_levels<WG>(layers, sh, log_leaf, levels, active);
+    upq_levels<WG>(layers, sh, log_leaf, levels, active, blockIdx.x);
     if (log_leaf == levels) chan_step_from_lds(hk, sh);
 }
 
@@ -698,6 +741,7 @@ int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_sto
     uint8_t *layers = (uint8_t *)ts.t[0];             // (the one-lane scheme kept for A/B timing handles one tree)
     static const bool one_lane = getenv("TSTWO_MERKLE_UP_ONELANE") != nullptr;     // previous scheme, kept for A/B timing
     static const bool small_wg = getenv("TSTWO_MERKLE_UP_SMALLWG") != nullptr;     // 256-lane workgroups only (A/B timing)
+    static const bool narrow_first = getenv("TSTWO_MERKLE_UP_NARROW_FIRST") != nullptr;   // 64-quad workgroups first, one 256-quad workgroup last (A/B timing)
     while (log_child > log_stop) {
         const u32 remaining = log_child - log_stop;
         const u32 parents_log = log_child - 1;
@@ -710,6 +754,16 @@ int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_sto
                 hipLaunchKernelGGL(k_merkle_up<256>, dim3(1), dim3(256), 0, c.stream, (uint4 *)layers, log_child, remaining);
                 log_child -= remaining;
             }
+        } else if (parents_log >= 9 && remaining >= 9 && remaining <= 16 && !small_wg && !narrow_first) {
+            // 256 quads per workgroup, 9 levels each, FIRST: the wide levels (256 and 128 compressions on one CU are the slow
+            // part of a single-workgroup tree top) run on 2^(parents_log-8) CUs side by side, and what is left (<= 7 levels)
+            // fits one 64-quad workgroup, one wave per SIMD.  (The other order — 64-quad workgroups first, one 256-quad
+            // workgroup to finish — put those wide levels on one CU.)
+            hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1u << (parents_log - 8), n_trees), dim3(1024), 0, c.stream, ts, log_child, 9u, none);
+            log_child -= 9;
+        } else if (parents_log <= 6 && !narrow_first) {   // <= 64 parents: one 64-quad workgroup finishes the tree
+            hipLaunchKernelGGL(k_merkle_upq<256>, dim3(1, n_trees), dim3(256), 0, c.stream, ts, log_child, remaining, take_hook(log_stop == 0));
+            log_child -= remaining;
         } else if (parents_log <= 8 && !small_wg) {   // <= 256 parents: ONE workgroup of 256 quads finishes the tree (up to 9 levels)
             hipLaunchKernelGGL(k_merkle_upq<1024>, dim3(1, n_trees), dim3(1024), 0, c.stream, ts, log_child, remaining, take_hook(log_stop == 0));
             log_child -= remaining;
@@ -792,7 +846,7 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTail ft, const u32 *__rest
             reinterpret_cast<uint4 *>(sh)[2 * t + 1] = hi;
         }
         __syncthreads();
-        upq_levels<1024>(layers, sh, lg, lg, active);                // the root is in sh[0..7] afterwards
+        upq_levels<1024>(layers, sh, lg, lg, active, 0u);            // the root is in sh[0..7] afterwards
         // channel: mix the root, draw alpha (wave 0; channel/blake2.ts:115-184, Rust draw semantics)
         if (t < 64) {
             u32 f[4];
