@@ -57,7 +57,7 @@ def line_interpolate(evaluation: LineEvaluation, twiddles: TwiddleTree | None = 
     return [QM31.from_u32_unchecked(*row) for row in vals.T.tolist()]
 
 
-def line_interpolate_device(evaluation: LineEvaluation, twiddles: TwiddleTree) -> "L.DeviceBuffer | None":
+def line_interpolate_device(evaluation: LineEvaluation, twiddles: TwiddleTree, out: "L.DeviceBuffer | None" = None) -> "L.DeviceBuffer | None":
     """The same on the device (tstwo_line_interpolate: one workgroup, at most 2^12 values on a doubling of the twiddle tree's
     root): enqueues the kernel and returns the buffer of the four coefficient columns (4 x n words, coordinate-major) for the
     caller to fetch together with whatever else it reads back; None when the layer does not qualify."""
@@ -66,7 +66,8 @@ def line_interpolate_device(evaluation: LineEvaluation, twiddles: TwiddleTree) -
         return None
     if n >= 2 and not _line_interpolate_uses_tree(evaluation, twiddles):
         return None
-    out = L.DeviceBuffer(16 * n)
+    if out is None:
+        out = L.DeviceBuffer(16 * n)
     L.call("tstwo_line_interpolate", evaluation.values.ptrs(), n.bit_length() - 1, L.vp(twiddles.itwiddles.buf.ptr),
            twiddles.log_size, L.p4([out.ptr + 4 * n * k for k in range(4)]))
     return out
@@ -346,31 +347,37 @@ class FriProver:
                 first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _DeviceTranscript(dch, alphas))
             else:
                 first_layer, inner, layer_eval = FriProver._commit_layers_in_library(config, columns, twiddles, dch, alphas)
-            # what the host needs to finish — the channel state and the last layer's polynomial — in ONE round trip (six separate
-            # read-backs were 0.17 ms of a 0.76 ms commit).  The interpolation itself (LineEvaluation.interpolate) runs on the
-            # device when the layer fits one workgroup; otherwise its inputs (coordinate columns, x^-1 slice of the tree) come back.
-            n_last = layer_eval.len()
-            separate = bool(os.environ.get("TSTWO_FRI_SEPARATE_READBACKS"))   # A/B timing: round 3's first form, one tstwo_download per piece
-            coeff_buf = None if separate or os.environ.get("TSTWO_FRI_HOST_LAST_LAYER") else line_interpolate_device(layer_eval, twiddles)
-            pieces = [(dch.buf.ptr, 10)]
-            uses_tree = _line_interpolate_uses_tree(layer_eval, twiddles)
-            if coeff_buf is not None:
-                pieces.append((coeff_buf.ptr, 4 * n_last))
-            else:
-                pieces += [(c.buf.ptr, n_last) for c in layer_eval.values.columns]
-                if uses_tree:
-                    pieces.append((twiddles.itwiddles.buf.ptr + 4 * (twiddles.itwiddles.len() - n_last), n_last))
-            got = [L.download_many([pc])[0] for pc in pieces] if separate else L.download_many(pieces)
-            dch.sync_to_host(got[0])                                         # the host channel continues from the device state
-            if coeff_buf is not None:
-                prefetched = {"coeffs": got[1].reshape(4, n_last)}
-            else:
-                prefetched = (got[1:5], got[5] if uses_tree else None)
+            prefetched = FriProver._fetch_end_of_commit(dch, layer_eval, twiddles)
         else:
             first_layer, inner, layer_eval = FriProver._commit_layers(config, columns, twiddles, _HostTranscript(channel))
             prefetched = None
         last = FriProver._commit_last_layer(channel, config, layer_eval, twiddles, prefetched)
         return FriProver(config, first_layer, inner, last)
+
+    @staticmethod
+    def _fetch_end_of_commit(dch: DeviceChannel, layer_eval: LineEvaluation, twiddles: TwiddleTree, coeff_buf=None):
+        """What the host needs to finish a device-transcript commit — the channel state and the last layer's polynomial — in ONE
+        round trip (six separate read-backs were 0.17 ms of a 0.76 ms commit).  The interpolation itself
+        (LineEvaluation.interpolate) runs on the device when the layer fits one workgroup (coeff_buf: already enqueued by the
+        caller); otherwise its inputs (coordinate columns, x^-1 slice of the tree) come back.  Updates the host channel; returns
+        what _commit_last_layer takes as `prefetched`."""
+        n_last = layer_eval.len()
+        separate = bool(os.environ.get("TSTWO_FRI_SEPARATE_READBACKS"))   # A/B timing: round 3's first form, one tstwo_download per piece
+        if coeff_buf is None and not separate and not os.environ.get("TSTWO_FRI_HOST_LAST_LAYER"):
+            coeff_buf = line_interpolate_device(layer_eval, twiddles)
+        pieces = [(dch.buf.ptr, 10)]
+        uses_tree = _line_interpolate_uses_tree(layer_eval, twiddles)
+        if coeff_buf is not None:
+            pieces.append((coeff_buf.ptr, 4 * n_last))
+        else:
+            pieces += [(c.buf.ptr, n_last) for c in layer_eval.values.columns]
+            if uses_tree:
+                pieces.append((twiddles.itwiddles.buf.ptr + 4 * (twiddles.itwiddles.len() - n_last), n_last))
+        got = [L.download_many([pc])[0] for pc in pieces] if separate else L.download_many(pieces)
+        dch.sync_to_host(got[0])                                         # the host channel continues from the device state
+        if coeff_buf is not None:
+            return {"coeffs": got[1].reshape(4, n_last)}
+        return (got[1:5], got[5] if uses_tree else None)
 
     @staticmethod
     def _device_capable(columns, twiddles) -> bool:
@@ -587,10 +594,14 @@ class FriCommitPlan:
         self._dch = DeviceChannel(Blake2sChannel(), buf=self.chan)
         FriProver._commit_layers(config, self.columns, twiddles, _DeviceTranscript(self._dch, self.alphas))
         L.sync()
+        n_last = config.last_layer_domain_size()
+        self._coeff_buf = L.DeviceBuffer(16 * n_last) if n_last <= (1 << 12) else None      # (a capture cannot allocate)
         L.call("tstwo_graph_begin_capture")
         try:
             self.first_layer, self.inner, self.last_eval = FriProver._commit_layers(
                 config, self.columns, twiddles, _DeviceTranscript(self._dch, self.alphas))
+            if self._coeff_buf is not None:                       # the last layer's interpolation is part of the graph
+                self._coeff_buf = line_interpolate_device(self.last_eval, twiddles, out=self._coeff_buf)
         finally:
             h = C.c_void_p()
             L.call("tstwo_graph_end_capture", C.byref(h))
@@ -599,10 +610,14 @@ class FriCommitPlan:
     def run(self, channel) -> FriProver:
         self._dch.load(channel)                                   # host channel state -> device (64 bytes)
         L.call("tstwo_graph_launch", self._exec)
-        self._dch.sync_to_host()
+        if self._coeff_buf is not None:
+            prefetched = FriProver._fetch_end_of_commit(self._dch, self.last_eval, self.twiddles, coeff_buf=self._coeff_buf)
+        else:
+            self._dch.sync_to_host()
+            prefetched = None
         for layer in [self.first_layer] + self.inner:             # roots are re-read lazily from the freshly written layers
             layer.merkle_tree._root = None
-        last = FriProver._commit_last_layer(channel, self.config, self.last_eval, self.twiddles)
+        last = FriProver._commit_last_layer(channel, self.config, self.last_eval, self.twiddles, prefetched)
         return FriProver(self.config, self.first_layer, self.inner, last)
 
     def __del__(self):
