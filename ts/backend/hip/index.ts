@@ -263,6 +263,17 @@ export class HipFriOps {
       check(hip.tstwo_fri_fold_circle_into_line_tw(ptr(dst.values.ptrs()), BigInt(dst.len()), ptr(src.values.ptrs()), n, inv.dev, ptr(q4(alpha))));
     }
   }
+  /** LineEvaluation.interpolate (poly/line.ts:312-329) on the device for a layer of at most 2^12 values on a doubling of the
+   *  tree's root — the last FRI layer: returns the four coefficient columns (bit-reversed coefficient order) still in HBM; fetch
+   *  them together with the channel state in one `downloadMany` (ffi.ts). */
+  line_interpolate(ev: { values: HipSecureColumn; domain(): LineDomain; len(): number }, tw: TwiddleTree<HipBackend, HipColumn>): HipSecureColumn {
+    const domain = ev.domain(), k = domain.logSize();
+    if (k > 12) throw new Error("line_interpolate: at most 2^12 values on the device");
+    if (k >= 1 && !domain.coset().is_doubling_of(tw.rootCoset)) throw new Error("Not enough twiddles!");
+    const out = HipSecureColumn.uninitialized(ev.len());
+    check(hip.tstwo_line_interpolate(ptr(ev.values.ptrs()), k, tw.itwiddles.dev, tw.rootCoset.log_size, ptr(out.ptrs())));
+    return out;
+  }
   decompose(ev: { values: HipSecureColumn; domain: CircleDomain }): [SecureEvaluation<HipBackend, BitReversedOrder>, QM31] {
     const n = ev.values.len();
     const out = HipSecureColumn.uninitialized(n), lam = new Uint32Array(4);
