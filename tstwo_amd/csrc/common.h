@@ -156,7 +156,8 @@ int merkle_commit_then_channel(const u32 *const *cols, const u32 *log_sizes, siz
 int merkle_commit4_folded(const u32 *const prev[4], u32 log_new, const u32 *inv_x, const u32 *alpha_dev, u32 *const new_cols[4],
                           uint8_t *layers, u32 *chan, u32 *felt);
 // merkle.hip: the FRI commit's last layers (2^log0 <= 2^9 rows and below) in one single-workgroup launch
-int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas);
+int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas,
+                    const u32 *const *pre, const u32 *pre_alpha);
 // Host: describe columns [0, n_cols) of `cols` in `out`; slot 0/1 = which of the two device tables to use when a launch needs two.
 int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot);
 constexpr int kMaxHashCols = 256;        // Merkle: columns absorbed per launch (multiple of 16)

@@ -516,6 +516,8 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
     uint8_t *cur_tree = nullptr;         // set: `cur` is already committed into it (its leaves were hashed by the fold that produced it)
                                          // and alpha (n + 1) is drawn
     uint8_t *spare_tree = nullptr;       // a tree buffer of the current size allocated for a fusion that an override refused
+    const u32 *tail_pre[4] = {nullptr, nullptr, nullptr, nullptr};      // set: `cur` is still to be computed — the tail launch folds it
+    const u32 *tail_pre_alpha = nullptr;                                // from this evaluation with this alpha (one launch fewer)
     while (cur_log > log_last_layer_size) {
         if (!cur_tree && !no_tail && cur_log <= 9 && nxt == n_columns) {
             // every remaining layer fits one workgroup's LDS: ONE launch does tree / mix / draw / fold for all of them (k_fri_tail)
@@ -530,7 +532,8 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
                 if ((rc = alloc_eval(ev[i + 1], cur_log - i - 1))) return fail(rc);
             }
             spare_tree = nullptr;
-            if ((rc = launch_fri_tail(ev, trees, nl, cur_log, itw, tw_log, chan, alphas + 4 * (n + 1)))) return fail(rc);
+            if ((rc = launch_fri_tail(ev, trees, nl, cur_log, itw, tw_log, chan, alphas + 4 * (n + 1), tail_pre_alpha ? tail_pre : nullptr, tail_pre_alpha)))
+                return fail(rc);
             for (u32 i = 0; i < nl; i++) {
                 out[n].log_size = cur_log - i;
                 for (int k = 0; k < 4; k++) out[n].cols[k] = ev[i][k];
@@ -574,7 +577,10 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
             else if (rc) return fail(rc);
             else { cur_tree = (uint8_t *)t; fused = true; }
         }
-        if (!fused && (rc = tstwo_fri_fold_line_dev(cur, cur_log, itw, tw_log, alpha, folded))) return fail(rc);
+        if (!fused && tail_next && !joins && next_log > log_last_layer_size) {
+            for (int k = 0; k < 4; k++) tail_pre[k] = cur[k];          // the tail launch folds this layer on its way in
+            tail_pre_alpha = alpha;
+        } else if (!fused && (rc = tstwo_fri_fold_line_dev(cur, cur_log, itw, tw_log, alpha, folded))) return fail(rc);
         for (int k = 0; k < 4; k++) cur[k] = folded[k];
         cur_log = next_log;
         n++;

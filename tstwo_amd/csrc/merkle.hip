@@ -816,11 +816,14 @@ struct FriTail {
     u32 *eval[11][4];        // eval[0]: the input evaluation (2^log0 rows, already folded); eval[i + 1]: output of fold i
     uint4 *tree[10];         // tree[i]: layers buffer of the tree over eval[i]
     u32 n_layers, log0;
+    const u32 *pre[4];       // non-null: eval[0] is still to be computed — the fold_line of this evaluation of 2^(log0+1) rows with
+    const u32 *pre_alpha;    // the alpha at pre_alpha (drawn by an earlier launch); the kernel writes eval[0]
 };
 __global__ void __launch_bounds__(1024) k_fri_tail(FriTail ft, const u32 *__restrict__ itw, u32 tw_log, u32 *__restrict__ chan,
                                                   u32 *__restrict__ alphas) {
     constexpr u32 Q = 256;
     __shared__ __attribute__((aligned(16))) u32 sh[Q * 16];
+    __shared__ __attribute__((aligned(16))) u32 evl[4][512];         // the current layer's evaluation, coordinate-major
     __shared__ u32 alpha_sh[4];
     const u32 t = threadIdx.x;
     u32 d[8], n_chal = 0, n_sent = 0;
@@ -829,15 +832,36 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTail ft, const u32 *__rest
         for (int k = 0; k < 8; k++) d[k] = chan[k];
         n_chal = chan[8]; n_sent = chan[9];
     }
+    // Between the layers the evaluation never goes through memory: row t of the next layer is computed by lane t — the lane that
+    // hashes leaf t of the next tree (registers) — and the fold reads rows 2t, 2t+1 from LDS.  (The first form read the folded
+    // rows back from global memory behind a device-scope fence, twice per layer: most of a layer's time outside its tree levels.)
+    u32 row[4] = {0u, 0u, 0u, 0u};
+    if (t < (1u << ft.log0)) {
+        if (ft.pre_alpha) {          // the fold into the first layer of the tail rides along (one launch fewer)
+            const qm31 alpha = *reinterpret_cast<const qm31 *>(ft.pre_alpha);
+            const u32 tw0 = gload1(itw + ((size_t)1 << tw_log) - ((size_t)2 << ft.log0) + t);
+            const uint2 a = gload2(ft.pre[0] + 2 * t), b = gload2(ft.pre[1] + 2 * t), c = gload2(ft.pre[2] + 2 * t), e = gload2(ft.pre[3] + 2 * t);
+            const qm31 f0 = {m31_add(a.x, a.y), m31_add(b.x, b.y), m31_add(c.x, c.y), m31_add(e.x, e.y)};
+            const qm31 f1 = qm31_mul_m31({m31_sub(a.x, a.y), m31_sub(b.x, b.y), m31_sub(c.x, c.y), m31_sub(e.x, e.y)}, tw0);
+            const qm31 r0 = qm31_add(f0, qm31_mul(alpha, f1));
+            row[0] = r0.a; row[1] = r0.b; row[2] = r0.c; row[3] = r0.d;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) { gstore1(ft.eval[0][c2] + t, row[c2]); evl[c2][t] = row[c2]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) { row[c] = gload1(ft.eval[0][c] + t); evl[c][t] = row[c]; }
+        }
+    }
     for (u32 i = 0; i < ft.n_layers; i++) {
         const u32 lg = ft.log0 - i;                                  // 1 <= lg <= 9
-        const u32 *c0 = ft.eval[i][0], *c1 = ft.eval[i][1], *c2 = ft.eval[i][2], *c3 = ft.eval[i][3];
         uint4 *layers = ft.tree[i];
-        // tree over the 4 coordinate columns (vcs/blake2_merkle.ts:9-24): leaves, then all levels
         const u32 active = 1u << (lg - 1);
+        // the fold's x^-1 of this layer: requested now, used behind the tree and the channel step
+        const u32 tw = t < active ? gload1(itw + ((size_t)1 << tw_log) - ((size_t)1 << lg) + t) : 0u;
+        // tree over the 4 coordinate columns (vcs/blake2_merkle.ts:9-24): leaves, then all levels
         if (t < 2 * active) {
             u32 h[8] = {IV0 ^ 0x01010020u, IV1, IV2, IV3, IV4, IV5, IV6, IV7};
-            const u32 m[16] = {gload1(c0 + t), gload1(c1 + t), gload1(c2 + t), gload1(c3 + t), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const u32 m[16] = {row[0], row[1], row[2], row[3], 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             b2s_compress(h, m, 16u, true);
             uint4 *leaf = layers + 2 * ((((size_t)1 << lg) - 1) + t);
             const uint4 lo = make_uint4(h[0], h[1], h[2], h[3]), hi = make_uint4(h[4], h[5], h[6], h[7]);
@@ -845,7 +869,7 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTail ft, const u32 *__rest
             reinterpret_cast<uint4 *>(sh)[2 * t] = lo;
             reinterpret_cast<uint4 *>(sh)[2 * t + 1] = hi;
         }
-        __syncthreads();
+        lds_only_barrier();
         upq_levels<1024>(layers, sh, lg, lg, active, 0u);            // the root is in sh[0..7] afterwards
         // channel: mix the root, draw alpha (wave 0; channel/blake2.ts:115-184, Rust draw semantics)
         if (t < 64) {
@@ -857,20 +881,23 @@ __global__ void __launch_bounds__(1024) k_fri_tail(FriTail ft, const u32 *__rest
                 alphas[4 * i + t] = v;
             }
         }
-        __syncthreads();
-        // fold_line (fri.ts:120-152): row r of the next evaluation
+        lds_only_barrier();
+        // fold_line (fri.ts:120-152): row t of the next evaluation from rows 2t, 2t + 1 of this one
+        qm31 r = {0u, 0u, 0u, 0u};
         if (t < active) {
             const qm31 alpha = {alpha_sh[0], alpha_sh[1], alpha_sh[2], alpha_sh[3]};
-            const u32 tw = itw[((size_t)1 << tw_log) - ((size_t)1 << lg) + t];
-            const uint2 a = gload2(c0 + 2 * t), b = gload2(c1 + 2 * t), c = gload2(c2 + 2 * t), e = gload2(c3 + 2 * t);
+            const uint2 a = *reinterpret_cast<const uint2 *>(&evl[0][2 * t]), b = *reinterpret_cast<const uint2 *>(&evl[1][2 * t]),
+                        c = *reinterpret_cast<const uint2 *>(&evl[2][2 * t]), e = *reinterpret_cast<const uint2 *>(&evl[3][2 * t]);
             const qm31 f0 = {m31_add(a.x, a.y), m31_add(b.x, b.y), m31_add(c.x, c.y), m31_add(e.x, e.y)};
             const qm31 f1 = qm31_mul_m31({m31_sub(a.x, a.y), m31_sub(b.x, b.y), m31_sub(c.x, c.y), m31_sub(e.x, e.y)}, tw);
-            const qm31 r = qm31_add(f0, qm31_mul(alpha, f1));
+            r = qm31_add(f0, qm31_mul(alpha, f1));
             gstore1(ft.eval[i + 1][0] + t, r.a); gstore1(ft.eval[i + 1][1] + t, r.b);
             gstore1(ft.eval[i + 1][2] + t, r.c); gstore1(ft.eval[i + 1][3] + t, r.d);
         }
-        __threadfence();                 // the next layer's leaves are read by other lanes of this workgroup
-        __syncthreads();
+        lds_only_barrier();              // every lane has read its two rows of this layer
+        if (t < active) { evl[0][t] = r.a; evl[1][t] = r.b; evl[2][t] = r.c; evl[3][t] = r.d; }
+        row[0] = r.a; row[1] = r.b; row[2] = r.c; row[3] = r.d;
+        lds_only_barrier();
     }
     if (t == 0) {
 #pragma unroll
@@ -1017,7 +1044,8 @@ int merkle_commit4_folded(const u32 *const prev[4], u32 log_new, const u32 *inv_
     return consumed ? TSTWO_OK : set_error(TSTWO_ERR_HIP, "fri commit: the fold was not carried by the leaf launch");
 }
 // fri.hip's commit loop hands the layers from 2^log0 <= 2^9 rows down to the last one to k_fri_tail (see there).
-int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas) {
+int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, u32 log0, const u32 *itw, u32 tw_log, u32 *chan, u32 *alphas,
+                    const u32 *const *pre, const u32 *pre_alpha) {
     if (n_layers == 0 || n_layers > 10 || log0 < n_layers || log0 > 9 || log0 - n_layers + 1 < 1)
         return set_error(TSTWO_ERR_BAD_ARG, "fri tail: layer range out of bounds");
     FriTail ft = {};
@@ -1026,6 +1054,11 @@ int launch_fri_tail(u32 *const (*eval)[4], uint8_t *const *trees, u32 n_layers, 
     for (u32 i = 0; i < n_layers; i++) ft.tree[i] = (uint4 *)trees[i];
     ft.n_layers = n_layers;
     ft.log0 = log0;
+    if (pre && pre_alpha) {
+        if (tw_log > 31 || log0 + 1 > tw_log) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
+        for (int k = 0; k < 4; k++) ft.pre[k] = pre[k];
+        ft.pre_alpha = pre_alpha;
+    }
     hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(1024), 0, ctx().stream, ft, itw, tw_log, chan, alphas);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
