@@ -52,6 +52,12 @@ int read_and_clear_flag(u32 *value);
 // small_h2d copies the source into a ring slot and returns with the transfer enqueued (stream-ordered, no host sync) for
 // sizes up to kUpSlotBytes, and synchronises for larger ones.
 int small_d2h(void *host_dst, const void *dev_src, size_t bytes);
+// Small results without the copy: a kernel writes them straight into the result page (page-locked host memory mapped into the
+// device, kResultBytes), and the read-back is one stream synchronisation.  result_target: the page's device address when `bytes`
+// fit (and the page exists), else nullptr — the caller then goes through device scratch + small_d2h.  result_wait: synchronises
+// and returns the page as the host sees it.
+void *result_target(size_t bytes);
+int result_wait(const void **host_view);
 int small_h2d(void *dev_dst, const void *host_src, size_t bytes);
 
 #define TSTWO_HIP(call)                                        \

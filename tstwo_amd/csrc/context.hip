@@ -63,6 +63,16 @@ int small_d2h(void *host_dst, const void *dev_src, size_t bytes) {
     memcpy(host_dst, c.pinned, bytes);
     return TSTWO_OK;
 }
+void *result_target(size_t bytes) {
+    Context &c = g_ctx;
+    return (c.result_dev && bytes <= kResultBytes) ? c.result_dev : nullptr;
+}
+int result_wait(const void **host_view) {
+    Context &c = g_ctx;
+    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    *host_view = c.result_host;
+    return TSTWO_OK;
+}
 // A host-array upload cannot be part of a captured graph: the memcpy node would read a ring slot (or the caller's array) at
 // REPLAY time, long after it has been overwritten, and the slot's event would become a captured event.  Fail loudly instead
 // (include/tstwo_hip.h, "Rules while capturing").

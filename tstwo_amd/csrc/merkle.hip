@@ -1112,9 +1112,17 @@ int tstwo_gather_words(const void *const *srcs, const uint64_t *idx, u32 words, 
     rc = small_h2d(c.scratch, h, n_items * sizeof(GatherItem));     // stream-ordered behind whatever still reads the scratch
     delete[] h;
     if (rc) return rc;
-    u32 *d_out = (u32 *)((unsigned char *)c.scratch + items_bytes);
+    u32 *const page = (u32 *)result_target(total * sizeof(u32));
+    u32 *d_out = page ? page : (u32 *)((unsigned char *)c.scratch + items_bytes);
     hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(total, 256)), dim3(256), 0, c.stream, (const GatherItem *)c.scratch, words, total, d_out);
     TSTWO_LAUNCH_CHECK();
+    if (page) {
+        const void *view = nullptr;
+        rc = result_wait(&view);
+        if (rc) return rc;
+        memcpy(host_out, view, total * sizeof(u32));
+        return TSTWO_OK;
+    }
     return small_d2h(host_out, d_out, total * sizeof(u32));
 }
 
@@ -1188,13 +1196,22 @@ static int run_decommit(const DecommitLists &l, u32 *queried_values, uint8_t *ha
     rc = small_h2d(c.scratch, items.data(), items.size() * sizeof(GatherItem));
     if (rc) return rc;
     const GatherItem *d_items = (const GatherItem *)c.scratch;
-    u32 *d_out = (u32 *)((unsigned char *)c.scratch + items_bytes);
+    // the gathers write straight into the result page when the words fit: the read-back is a synchronisation, not a copy
+    u32 *const page = (u32 *)result_target(out_words * sizeof(u32));
+    u32 *d_out = page ? page : (u32 *)((unsigned char *)c.scratch + items_bytes);
     if (nh) hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(8 * nh, 256)), dim3(256), 0, c.stream, d_items, 8u, 8 * nh, d_out);
     if (nv) hipLaunchKernelGGL(k_gather_words, dim3(ceil_div(nv, 256)), dim3(256), 0, c.stream, d_items + nh, 1u, nv, d_out + 8 * nh);
     TSTWO_LAUNCH_CHECK();
     std::vector<u32> host(out_words);
-    rc = small_d2h(host.data(), d_out, out_words * sizeof(u32));
-    if (rc) return rc;
+    if (page) {
+        const void *view = nullptr;
+        rc = result_wait(&view);
+        if (rc) return rc;
+        memcpy(host.data(), view, out_words * sizeof(u32));
+    } else {
+        rc = small_d2h(host.data(), d_out, out_words * sizeof(u32));
+        if (rc) return rc;
+    }
     if (nh - n_extra) memcpy(hash_witness, host.data(), 32 * (nh - n_extra));
     if (n_extra) memcpy(extra, host.data() + 8 * (nh - n_extra), 32 * n_extra);
     if (nq) memcpy(queried_values, host.data() + 8 * nh, 4 * nq);
