@@ -463,3 +463,34 @@ def test_decommit_requests_planner_against_oracle_tree():
     bad = T.MerkleDecommitment([hashes[0][::-1]] + hashes[1:], colwit)
     with pytest.raises(ValueError, match="Root mismatch"):
         T.MerkleVerifier(T.Blake2sMerkleHasher, root, logs).verify(queries, queried, bad)
+
+
+def test_lazy_proof_sequences_behave_like_lists():
+    """M31Values / HashSlices (vcs.py): what a decommitment holds until somebody looks at it — list semantics for readers, and a
+    real list from the first mutation on (the verifier tests tamper with proofs)."""
+    import copy
+
+    from tstwo_amd.fields import M31
+    from tstwo_amd.vcs import HashSlices, M31Values
+    m = M31Values([5, 6, 7])
+    assert len(m) == 3 and m[0] == M31(5) and m[-1] == M31(7) and m[1:] == [M31(6), M31(7)]
+    assert list(m) == [M31(5), M31(6), M31(7)] and m == [M31(5), M31(6), M31(7)]
+    assert m + [M31(1)] == [M31(5), M31(6), M31(7), M31(1)] and [M31(1)] + m == [M31(1), M31(5), M31(6), M31(7)]
+    with pytest.raises(IndexError):
+        m[3]
+    d = copy.deepcopy(m)
+    d.append(M31(9)); d[0] = M31(0)
+    assert len(d) == 4 and d[0] == M31(0) and d.pop() == M31(9) and len(m) == 3 and m[0] == M31(5)
+    raw = bytes(range(96))
+    h = HashSlices(raw, 3)
+    assert len(h) == 3 and h[1] == raw[32:64] and h[-1] == raw[64:] and list(h) == [raw[:32], raw[32:64], raw[64:]]
+    g = copy.deepcopy(h)
+    g[2] = bytes(32); g.pop(0)
+    assert list(g) == [raw[32:64], bytes(32)] and list(h) == [raw[:32], raw[32:64], raw[64:]]
+
+
+def test_bit_reverse_perm_matches_bit_reverse_index():
+    from tstwo_amd.circle import bit_reverse_index, bit_reverse_perm
+    for lg in range(0, 11):
+        assert bit_reverse_perm(lg).tolist() == [bit_reverse_index(i, lg) for i in range(1 << lg)]
+    assert not bit_reverse_perm(5).flags.writeable
