@@ -591,6 +591,39 @@ def test_cfft_interpolate_to_matches_in_place(n):
     assert (dst[0].download() == evals[0]).all()
 
 
+def test_cfft_log23_two_pass_plan_vs_oracle():
+    """n = 23 is the one size whose default plan uses the 2^14-word bottom tile (14 + 9 layers, two passes): evaluate, interpolate,
+    the out-of-place interpolate and the fused extension (21 -> 23, 22 -> 23) against the oracle, every word."""
+    n = 23
+    half = half_odds(n - 1)
+    tw, itw = build_twiddles(n - 1)
+    otw, oitw = orc.precompute_twiddles(half, n - 1)
+    cols = [rand_column(23000 + c, 1 << n) for c in range(2)]
+    want = [orc.cfft_evaluate(c, n, half, otw, n - 1) for c in cols]
+    d = [dev(c) for c in cols]
+    L.call("tstwo_cfft_evaluate", ptrs(d), 2, n, half, vp(tw), n - 1)
+    for c in range(2):
+        assert (host(d[c], 1 << n) == want[c]).all(), f"evaluate col {c}"
+    # out-of-place interpolation of the evaluations gives the coefficients back and leaves the source untouched
+    dst = [L.DeviceBuffer(4 << n) for _ in cols]
+    L.call("tstwo_cfft_interpolate_to", ptrs(d), ptrs(dst), 2, n, half, vp(itw), n - 1)
+    for c in range(2):
+        assert (dst[c].download() == cols[c]).all() and (host(d[c], 1 << n) == want[c]).all()
+    # in-place interpolation of arbitrary values against the oracle
+    vals = rand_column(23100, 1 << n)
+    dv = [dev(vals)]
+    L.call("tstwo_cfft_interpolate", ptrs(dv), 1, n, half, vp(itw), n - 1)
+    assert (host(dv[0], 1 << n) == orc.cfft_interpolate(vals, n, half, oitw, n - 1)).all()
+    # fused extension: polynomials of log 21 / 22 evaluated on the log-23 domain == zero-padded coefficients transformed
+    for log_poly in (21, 22):
+        poly = rand_column(23200 + log_poly, 1 << log_poly)
+        padded = np.zeros(1 << n, dtype=np.uint32)
+        padded[:1 << log_poly] = poly
+        out, src = [L.DeviceBuffer(4 << n)], [dev(poly)]
+        L.call("tstwo_cfft_evaluate_extended", ptrs(src), log_poly, ptrs(out), 1, n, half, vp(tw), n - 1)
+        assert (out[0].download() == orc.cfft_evaluate(padded, n, half, otw, n - 1)).all(), f"extended {log_poly} -> 23"
+
+
 @pytest.mark.parametrize("n", [25, 26, 27, 28, 29, 30])
 def test_cfft_maximum_sizes(n):
     """The largest transforms the tiled path plans, up to the reference's MAX_CIRCLE_DOMAIN_LOG_SIZE = 30

@@ -370,6 +370,12 @@ int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA, u3
     return cnt;
 }
 
+// Bottom tile of the default plan.  2^13 words everywhere but at n = 23, where a 2^14-word tile (1024 lanes, 72 KiB of LDS) makes
+// the transform 14 + 9 layers = TWO passes over memory instead of 13 + 5 + 5 = three: 16 x 2^23 in 499 against 650 us forward,
+// 532 against 667 us inverse.  At n = 22 the larger tile loses (14 + 8: 240 against 228 us), at n >= 24 nothing changes the pass
+// count (a 10-layer strided pass with 64-byte rows costs what it saves).
+inline u32 default_bottom_log(u32 n) { return n == 23 ? 14u : kMaxLogTileB; }
+
 template <bool INV, int THREADS>
 int launch_pass_t(u32 *const *cols, size_t n_cols, const PassParams &pp0) {
     Context &c = ctx();
@@ -526,6 +532,7 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         const size_t tiles = (size_t)1 << (n - ps.k);
         const size_t lds = (((size_t)1 << ps.k) + ((size_t)1 << (ps.k - 5)) + ((size_t)1 << (ps.k - 4))) * sizeof(u32);
         switch (ps.k) {
+            case 14: return launch_fast_kernel(fast::k_cfft_b<INV, 14>, 1024, lds, tiles, cols, n_cols, n, tw_end, scale);
             case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale);
             case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale);
             case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale);
@@ -599,10 +606,10 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
     if (tw_log > 31 || ((size_t)1 << (n - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     Pass passes[8];
-    u32 kb = kMaxLogTileB, ka_max = kMaxKA;
-    {   // tuning knobs (experiments): bottom-pass size 11..13, strided-pass limit 9..11
+    u32 kb = default_bottom_log(n), ka_max = kMaxKA;
+    {   // tuning knobs (experiments): bottom-pass size 11..14, strided-pass limit 1..10
         const char *e1 = getenv("TSTWO_CFFT_KB"), *e2 = getenv("TSTWO_CFFT_KA");
-        if (e1 && atoi(e1) >= 11 && atoi(e1) <= 13) kb = (u32)atoi(e1);
+        if (e1 && atoi(e1) >= 11 && atoi(e1) <= 14) kb = (u32)atoi(e1);
         if (e2 && atoi(e2) >= 1 && atoi(e2) <= 10) ka_max = (u32)atoi(e2);
     }
     u32 logta = kLogTileA;
@@ -695,14 +702,16 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
         if (((uintptr_t)itw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
         Context &c = ctx();
         Pass passes[8];
-        const int np = plan_passes(log_size, passes);
+        const u32 kb = default_bottom_log(log_size);
+        const int np = plan_passes(log_size, passes, kb);
         const u32 *tw_end = itw + ((size_t)1 << tw_log);
         const u32 n_inv = host::inv((1u << log_size) % M31_P);
         // bottom pass, out of place
         {
-            const size_t tiles = (size_t)1 << (log_size - 13);
-            const size_t lds = (((size_t)1 << 13) + ((size_t)1 << 8) + ((size_t)1 << 9)) * sizeof(u32);
-            auto kernel = fast::k_cfft_b<true, 13, true>;
+            const size_t tiles = (size_t)1 << (log_size - kb);
+            const size_t lds = (((size_t)1 << kb) + ((size_t)1 << (kb - 5)) + ((size_t)1 << (kb - 4))) * sizeof(u32);
+            const unsigned threads = 1u << (kb - 4);
+            auto kernel = kb == 14 ? fast::k_cfft_b<true, 14, true> : fast::k_cfft_b<true, 13, true>;
             { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
             {
                 const size_t cnt = n_cols;
@@ -712,8 +721,8 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
                 if (rc_tab) return rc_tab;
                 const size_t items = tiles * cnt;
                 if (items > 0xffffffffu) return set_error(TSTWO_ERR_BAD_ARG, "cfft: too many (tile, column) work items");
-                const unsigned blocks = plan_grid((const void *)kernel, 512, lds, items);
-                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(512), lds, c.stream, cp, sp, (u32)cnt, (u32)items, log_size, tw_end,
+                const unsigned blocks = plan_grid((const void *)kernel, (int)threads, lds, items);
+                hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds, c.stream, cp, sp, (u32)cnt, (u32)items, log_size, tw_end,
                                    np == 1 ? n_inv : 0u);
             }
             TSTWO_LAUNCH_CHECK();
@@ -748,7 +757,7 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
     int np = 0;
     const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
                        !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_FUSED_EXTEND");
-    if (tiled) np = plan_passes(log_size, passes);
+    if (tiled) np = plan_passes(log_size, passes, default_bottom_log(log_size));
     if (tiled && np >= 2 && (ext == 1 || ext == 2) && passes[np - 1].k >= 2) {
         if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
         if (tw_log > 31 || ((size_t)1 << (log_size - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
