@@ -374,7 +374,9 @@ int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA, u3
 // the transform 14 + 9 layers = TWO passes over memory instead of 13 + 5 + 5 = three: 16 x 2^23 in 499 against 650 us forward,
 // 532 against 667 us inverse.  At n = 22 the larger tile loses (14 + 8: 240 against 228 us), at n >= 24 nothing changes the pass
 // count (a 10-layer strided pass with 64-byte rows costs what it saves).
-inline u32 default_bottom_log(u32 n) { return n == 23 ? 14u : kMaxLogTileB; }
+// n = 14 likewise is ONE pass on the 2^14 tile instead of 13 + 1 (256 columns 16.4 against 21.2 us, 2048 columns 84 against 115 us;
+// a handful of columns: the same 12 us either way).
+inline u32 default_bottom_log(u32 n) { return (n == 23 || n == 14) ? 14u : kMaxLogTileB; }
 
 template <bool INV, int THREADS>
 int launch_pass_t(u32 *const *cols, size_t n_cols, const PassParams &pp0) {
@@ -613,7 +615,7 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
         if (e2 && atoi(e2) >= 1 && atoi(e2) <= 10) ka_max = (u32)atoi(e2);
     }
     u32 logta = kLogTileA;
-    if (n >= kLogTileA && !getenv("TSTWO_CFFT_KB") && !getenv("TSTWO_CFFT_KA")) {     // n = 13 is one bottom pass whatever the column count
+    if (n > kb && n >= kLogTileA && !getenv("TSTWO_CFFT_KB") && !getenv("TSTWO_CFFT_KA")) {     // n = 13 (and 14) is one bottom pass whatever the column count
         // Few columns: the default tiles (2^13 contiguous, 2^14 strided) give 2^(n-13) x cols and 2^(n-14) x cols workgroups;
         // below ~2 per CU pick the split with the most workgroups in its emptier pass (ties: the larger tiles).
         // n = 20, one column: 12 + 8 layers on 2^12-word tiles = 256 + 256 workgroups instead of 128 + 64.
@@ -757,7 +759,7 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
     int np = 0;
     const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
                        !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_FUSED_EXTEND");
-    if (tiled) np = plan_passes(log_size, passes, default_bottom_log(log_size));
+    if (tiled) np = plan_passes(log_size, passes, log_size == 14 ? kMaxLogTileB : default_bottom_log(log_size));   // (n = 14: 13 + 1 keeps the fused extension)
     if (tiled && np >= 2 && (ext == 1 || ext == 2) && passes[np - 1].k >= 2) {
         if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
         if (tw_log > 31 || ((size_t)1 << (log_size - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
