@@ -11,7 +11,11 @@ n, NC = 22, 32
 domain = T.CanonicCoset(n).circleDomain()
 cols = [T.HipColumn(rng.integers(0, T.P, size=1 << n, dtype=np.uint32)) for _ in range(NC)]
 pt = T.SECURE_FIELD_CIRCLE_GEN
-samples = [[PointSample(pt, T.QM31.from_u32_unchecked(*map(int, rng.integers(0, T.P, size=4))))] for _ in range(NC)]
+NPTS = int(os.environ.get("NPTS", "1"))          # sample points per column (= batches)
+pts = [pt]
+for _ in range(NPTS - 1):
+    pts.append(pts[-1].add(T.SECURE_FIELD_CIRCLE_GEN))
+samples = [[PointSample(p_, T.QM31.from_u32_unchecked(*map(int, rng.integers(0, T.P, size=4)))) for p_ in pts] for _ in range(NC)]
 coeff = T.QM31.from_u32_unchecked(1, 2, 3, 4)
 for _ in range(3):
     t0 = time.perf_counter(); batches = column_sample_batches(samples); t1 = time.perf_counter()
