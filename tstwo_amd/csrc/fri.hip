@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256) k_eval_partials(const qm31 *__restrict__ 
 
 unsigned capped_blocks(size_t work_items, unsigned threads) {
     unsigned blocks = ceil_div(work_items, threads);
-    unsigned cap = (unsigned)ctx().n_cus * 8;
+    static const unsigned mult = getenv("TSTWO_FOLD_CAP") ? (unsigned)atoi(getenv("TSTWO_FOLD_CAP")) : 64u;     // workgroups per CU before lanes grid-stride (8: fold_circle log 24 102 us, fold_line log 23 33.5 us; 32-1024: 97 / 32.5 us)
+    unsigned cap = (unsigned)ctx().n_cus * mult;
     if (blocks > cap) blocks = cap;
     return blocks ? blocks : 1;
 }
