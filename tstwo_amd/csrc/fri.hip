@@ -105,6 +105,8 @@ __global__ void __launch_bounds__(256) k_line_interpolate(CSoa4 in, Soa4 out, u3
 }
 
 // backend/cpu/fri.ts:97-123: sums of the two halves of each coordinate column (exact in u64).
+// VEC: 16-byte loads (columns 16-byte aligned, halves a multiple of 4 words).
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_half_sums(CSoa4 in, size_t n, unsigned long long *sums /* [4][2] */) {
     __shared__ unsigned long long sh[256 / 64];
     const u32 coord = blockIdx.y, halfsel = blockIdx.z;
@@ -113,7 +115,14 @@ __global__ void __launch_bounds__(256) k_half_sums(CSoa4 in, size_t n, unsigned 
     const size_t cnt = halfsel ? n - half : half;
     unsigned long long acc = 0;
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) acc += p[i];
+    if (VEC) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt / 4; i += stride) {
+            const uint4 v = gload4(p + 4 * i);
+            acc += (unsigned long long)v.x + v.y + ((unsigned long long)v.z + v.w);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) acc += p[i];
+    }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -123,14 +132,24 @@ __global__ void __launch_bounds__(256) k_half_sums(CSoa4 in, size_t n, unsigned 
     }
 }
 // backend/cpu/fri.ts:133-164: g = f - lambda on the first half, f + lambda on the second (n == 1: f - lambda)
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_decompose_apply(CSoa4 in, Soa4 out, size_t n, qm31 lambda) {
     const u32 coord = blockIdx.y;
     const u32 lam = coord == 0 ? lambda.a : coord == 1 ? lambda.b : coord == 2 ? lambda.c : lambda.d;
     const size_t half = n / 2;
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        u32 v = in.p[coord][i];
-        out.p[coord][i] = (i < half || n == 1) ? m31_sub(v, lam) : m31_add(v, lam);
+    if (VEC) {              // n >= 8: the 4 words of a vector lie in one half
+        const u32 nlam = m31_neg(lam);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+            const uint4 v = gload4(in.p[coord] + 4 * i);
+            const u32 add = 4 * i < half ? nlam : lam;          // f - lambda = f + (-lambda)
+            gstore4(out.p[coord] + 4 * i, make_uint4(m31_add(v.x, add), m31_add(v.y, add), m31_add(v.z, add), m31_add(v.w, add)));
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            u32 v = in.p[coord][i];
+            out.p[coord][i] = (i < half || n == 1) ? m31_sub(v, lam) : m31_add(v, lam);
+        }
     }
 }
 
@@ -607,10 +626,13 @@ int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32
     TSTWO_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(unsigned long long), c.stream));
     CSoa4 i4 = {{in[0], in[1], in[2], in[3]}};
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
+    bool vec = n >= 8 && n % 8 == 0;              // both halves whole 16-byte vectors
+    for (int k = 0; k < 4; k++) vec = vec && ((((uintptr_t)in[k]) | ((uintptr_t)out[k])) & 15) == 0;
     unsigned blocks = ceil_div(n, 256 * 16);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;           // (x 4 coordinates x 2 halves; every workgroup ends in one 64-bit atomic on one of 8 words: 4096 of them per word cost 0.25 ms)
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(k_half_sums, dim3(blocks, 4, 2), dim3(256), 0, c.stream, i4, n, sums);
+    if (vec) hipLaunchKernelGGL(k_half_sums<true>, dim3(blocks, 4, 2), dim3(256), 0, c.stream, i4, n, sums);
+    else hipLaunchKernelGGL(k_half_sums<false>, dim3(blocks, 4, 2), dim3(256), 0, c.stream, i4, n, sums);
     TSTWO_LAUNCH_CHECK();
     unsigned long long h[8];
     { int rc2 = small_d2h(h, sums, sizeof(h)); if (rc2) return rc2; }
@@ -623,7 +645,8 @@ int tstwo_fri_decompose(const u32 *const in[4], size_t n, u32 *const out[4], u32
         l[k] = host::mul(host::sub(a, b), n_inv);
     }
     lam = {l[0], l[1], l[2], l[3]};
-    hipLaunchKernelGGL(k_decompose_apply, dim3(capped_blocks(n, 256), 4), dim3(256), 0, c.stream, i4, o4, n, lam);
+    if (vec) hipLaunchKernelGGL(k_decompose_apply<true>, dim3(capped_blocks(n / 4, 256), 4), dim3(256), 0, c.stream, i4, o4, n, lam);
+    else hipLaunchKernelGGL(k_decompose_apply<false>, dim3(capped_blocks(n, 256), 4), dim3(256), 0, c.stream, i4, o4, n, lam);
     TSTWO_LAUNCH_CHECK();
     for (int k = 0; k < 4; k++) lambda[k] = l[k];
     return TSTWO_OK;
