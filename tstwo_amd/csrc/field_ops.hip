@@ -81,11 +81,20 @@ __global__ void __launch_bounds__(256) k_qm31_mul(CSoa4 a, CSoa4 b, Soa4 o, size
     }
 }
 // backend/cpu/accumulation.ts:38-49: col[k][i] += other[k][i]
+// VEC: 16-byte accesses (columns 16-byte aligned, n a multiple of 4)
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_secure_accumulate(Soa4 col, CSoa4 other, size_t n) {
     u32 *c = col.p[blockIdx.y];
     const u32 *o = other.p[blockIdx.y];
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c[i] = m31_add(c[i], o[i]);
+    if (VEC) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+            const uint4 x = gload4(c + 4 * i), y = gload4(o + 4 * i);
+            gstore4(c + 4 * i, make_uint4(m31_add(x.x, y.x), m31_add(x.y, y.y), m31_add(x.z, y.z), m31_add(x.w, y.w)));
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c[i] = m31_add(c[i], o[i]);
+    }
 }
 
 // ---------------------------------------------------------------- batch inverse
@@ -384,9 +393,15 @@ __global__ void __launch_bounds__(256) k_twiddles(u32 init, u32 m, u32 *__restri
     tw[e] = cpoint_from_index_win(idx, gen_pow2).x;      // gen_pow2 = Context::gen_win
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_extend(const u32 *__restrict__ src, size_t n_src, u32 *__restrict__ dst, size_t n_dst) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += stride) dst[i] = i < n_src ? src[i] : 0u;
+    if (VEC) {              // 16-byte accesses: both lengths multiples of 4, both buffers 16-byte aligned
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst / 4; i += stride)
+            gstore4(dst + 4 * i, 4 * i < n_src ? gload4(src + 4 * i) : make_uint4(0u, 0u, 0u, 0u));
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dst; i += stride) dst[i] = i < n_src ? src[i] : 0u;
+    }
 }
 
 unsigned capped_blocks(size_t work_items, unsigned threads) {
@@ -498,7 +513,10 @@ int tstwo_secure_accumulate(u32 *const col[4], const u32 *const other[4], size_t
     TSTWO_REQUIRE_TABLE(col, 4); TSTWO_REQUIRE_TABLE(other, 4);
     Soa4 c4 = {{col[0], col[1], col[2], col[3]}};
     CSoa4 o4 = {{other[0], other[1], other[2], other[3]}};
-    hipLaunchKernelGGL(k_secure_accumulate, dim3(capped_blocks(n, 256), 4), dim3(256), 0, ctx().stream, c4, o4, n);
+    bool vec = n % 4 == 0;
+    for (int k = 0; k < 4; k++) vec = vec && ((((uintptr_t)col[k]) | ((uintptr_t)other[k])) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(k_secure_accumulate<true>, dim3(capped_blocks(n / 4, 256), 4), dim3(256), 0, ctx().stream, c4, o4, n);
+    else hipLaunchKernelGGL(k_secure_accumulate<false>, dim3(capped_blocks(n, 256), 4), dim3(256), 0, ctx().stream, c4, o4, n);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
@@ -546,7 +564,10 @@ int tstwo_poly_extend(const u32 *src, u32 log_src, u32 *dst, u32 log_dst) {
     if (log_dst > 31) return set_error(TSTWO_ERR_BAD_ARG, "extend: log size out of range");
     if (log_dst < log_src) return set_error(TSTWO_ERR_LOG_SIZE, "log size too small");
     size_t ns = (size_t)1 << log_src, nd = (size_t)1 << log_dst;
-    hipLaunchKernelGGL(k_extend, dim3(capped_blocks(nd, 256)), dim3(256), 0, ctx().stream, src, ns, dst, nd);
+    if (log_src >= 2 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0)
+        hipLaunchKernelGGL(k_extend<true>, dim3(capped_blocks(nd / 4, 256)), dim3(256), 0, ctx().stream, src, ns, dst, nd);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(capped_blocks(nd, 256)), dim3(256), 0, ctx().stream, src, ns, dst, nd);
     TSTWO_LAUNCH_CHECK();
     return TSTWO_OK;
 }
