@@ -940,3 +940,30 @@ def test_download_many_errors():
         L.call("tstwo_download_many", srcs, (C.c_size_t * 1)(8), 1, C.c_void_p(0))
     L.call("tstwo_download_many", srcs, (C.c_size_t * 1)(0), 1, out.ctypes.data_as(C.c_void_p))       # nothing to fetch: fine
     assert len(L.download_many([])) == 0
+
+
+@pytest.mark.parametrize("log,n_cols", [(3, 2), (9, 5), (10, 4), (12, 9), (14, 33)])
+def test_quotients_two_batches_over_one_column_list(log, n_cols, golden):
+    """Every column opened at two points (two sample batches over the same column list): the kernel that loads the column words
+    once for both batches (k_quotients8_pair) against the oracle's per-row reference loop — and the same input with the second
+    batch's columns in another order, which takes the general kernel."""
+    px, py = golden["eval_at_point"][0]["point"]
+    py2 = OL.orc_qm31_mul(orc.q(py), orc.q(py)).tup()
+    cols = [rand_column(9100 + 7 * log + c, 1 << log) for c in range(n_cols)]
+    vals = [tuple(int(x) for x in rand_column(9500 + 3 * log + j, 4)) for j in range(2 * n_cols)]
+    d = [dev(c) for c in cols]
+    for second in (list(range(n_cols)), list(range(n_cols))[::-1]):
+        batches = [(px, py, [(c, vals[c]) for c in range(n_cols)]), (py, py2, [(c, vals[n_cols + i]) for i, c in enumerate(second)])]
+        off, cidx, points, values = [0], [], [], []
+        for bx, by, cv in batches:
+            points += [*bx, *by]
+            for ci, v in cv:
+                cidx.append(ci)
+                values += list(v)
+            off.append(len(cidx))
+        out = [L.DeviceBuffer(max(4 << log, 16)) for _ in range(4)]
+        L.call("tstwo_quotients_accumulate_samples", half_odds(log - 1), log, ptrs(d), n_cols, 2, L.u32x(off), L.u32x(cidx),
+               L.u32x(points), L.u32x(values), L.u32x((5, 6, 7, 8)), p4(out))
+        exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (5, 6, 7, 8), batches)
+        for k in range(4):
+            assert (host(out[k], 1 << log) == exp[k]).all(), (log, n_cols, second[:3], k)

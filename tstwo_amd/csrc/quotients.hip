@@ -265,6 +265,147 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
     }
 }
 
+// Two sample batches over the SAME column list (every column opened at two points, z and z·g: the common AIR shape).  The two
+// batches' numerators are sums over the same column words with different coefficients, so the words are loaded ONCE and feed both
+// (k_quotients8 reads every column again per batch: 32 columns x 2^22 took 0.235 ms for two batches against 0.149 for one, the
+// difference being the second trip of 512 MiB through memory).  Same arithmetic as k_quotients8<., LAZY> otherwise; the result
+// (0 * coeff_0 + term_0) * coeff_1 + term_1 of a half goes straight to memory.
+__global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
+                                                        const BatchConst *__restrict__ batches, const Entry *__restrict__ entries, Soa4 out,
+                                                        const cpoint *__restrict__ gen_pow2, cpoint qb, u32 bsel, u32 *flag) {
+    const size_t n_threads = (size_t)1 << (log_size - 3);
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_threads) return;
+    const u32 u4 = (u32)t << 2;
+    const u32 rowA = ((u4 >> bsel) << (bsel + 1)) | (u4 & ((1u << bsel) - 1u)), rowB = rowA + (1u << bsel);
+    u32 idx0 = (half_initial + __brev(rowA)) & 0x7fffffffu;
+    const cpoint p0 = cpoint_from_index_win(idx0, gen_pow2);
+    const cpoint p1 = cpoint_add(p0, qb);
+    u32 xy[8] = {p0.x, p1.x, p0.y, p1.y, p0.x, p1.x, p0.y, p1.y};
+    u32 yy[8] = {p0.y, p0.y, p0.y, p0.y, p1.y, p1.y, p1.y, p1.y};
+    bool zero = false;
+    u32 ir[2][8], ii[2][8], ay[2][8];
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const BatchConst bc = batches[b];
+        const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));
+        u32 m8[8] = {M31_P - bc.piy.a, M31_P - bc.piy.a, bc.pix.a, bc.pix.a, M31_P - bc.piy.b, M31_P - bc.piy.b, bc.pix.b, bc.pix.b}, pr[8];
+        f8::mul(pr, xy, m8);
+        u32 da[8], db[8], c8[8], tx[8], ty[8], u[8];
+        bcast(c8, c0.a);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { tx[s] = pr[s >> 2]; ty[s] = pr[2 + (s >> 2)]; }
+        f8::addsub<kSignX>(u, c8, tx);
+        f8::addsub<kSignY>(da, u, ty);
+        bcast(c8, c0.b);
+#pragma unroll
+        for (int s = 0; s < 8; s++) { tx[s] = pr[4 + (s >> 2)]; ty[s] = pr[6 + (s >> 2)]; }
+        f8::addsub<kSignX>(u, c8, tx);
+        f8::addsub<kSignY>(db, u, ty);
+        f8::done();
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            if ((da[s] | db[s]) == 0) { zero = true; da[s] = 1u; }
+        u64 nn[8];
+        u32 n[8], ninv[8], ndb[8];
+        f8::boundary<kPrioHeavy>(da, db);
+        f8::mul64(nn, da, da); f8::mad(nn, db, db);
+        f8::reduce<false>(n, nn);
+        f8::inverse8(ninv, n);
+        f8::neg_operand(ndb, db);
+        f8::mul(ir[b], da, ninv);
+        f8::mul(ii[b], ndb, ninv);
+        u32 a8[8] = {bc.A.a, bc.A.b, bc.A.c, bc.A.d, bc.A.a, bc.A.b, bc.A.c, bc.A.d};
+        f8::mul(ay[b], a8, yy);
+    }
+    const u32 begin0 = batches[0].begin, begin1 = batches[1].begin, n_entries = batches[0].end - batches[0].begin;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        u64 accq[2][2][8];
+#pragma unroll
+        for (int s = 0; s < 8; s++) accq[0][0][s] = accq[0][1][s] = accq[1][0][s] = accq[1][1][s] = 0ull;
+        u32 two = 2u;
+        asm volatile("" : "+v"(two));
+        for (u32 j = 0; j < n_entries; j += 4) {
+            const u32 cnt = min(4u, n_entries - j);                    // wave-uniform
+            u32 cw[2][4][4], f[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const u32 je = j + (e < (int)cnt ? e : 0);
+                const Entry en0 = entries[begin0 + je], en1 = entries[begin1 + je];          // same column, two coefficient sets
+                const uint4 fv = gload4(cols[en0.col], half ? rowB : rowA);
+                f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
+                const bool on = e < (int)cnt;
+                cw[0][e][0] = on ? en0.c.a : 0u; cw[0][e][1] = on ? en0.c.b : 0u; cw[0][e][2] = on ? en0.c.c : 0u; cw[0][e][3] = on ? en0.c.d : 0u;
+                cw[1][e][0] = on ? en1.c.a : 0u; cw[1][e][1] = on ? en1.c.b : 0u; cw[1][e][2] = on ? en1.c.c : 0u; cw[1][e][3] = on ? en1.c.d : 0u;
+            }
+            u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
+                            {f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]}};
+            f8::boundary<kPrioHeavy>(fp[0], fp[1]);
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        const int k = 2 * h + (s >> 2), r = s & 3;
+                        u64 a = (u64)(u32)(accq[b][h][s] >> 32) * (u64)two + (u64)(u32)accq[b][h][s];          // the fold (0 stays 0)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) a += (u64)cw[b][e][k] * (u64)fp[e >> 1][4 * (e & 1) + r];
+                        accq[b][h][s] = a;
+                    }
+            f8::pin(accq[0][0]); f8::pin(accq[0][1]); f8::pin(accq[1][0]); f8::pin(accq[1][1]);
+            f8::done();
+        }
+        u32 term[2][2][8];
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const BatchConst bc = batches[b];
+            u32 num[2][8];
+            f8::reduce(num[0], accq[b][0]);
+            f8::reduce(num[1], accq[b][1]);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                u32 b8[8], t8[8], nb[8], nq[8];
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int k = 2 * h + (s >> 2);
+                    b8[s] = k == 0 ? bc.B.a : k == 1 ? bc.B.b : k == 2 ? bc.B.c : bc.B.d;
+                    t8[s] = ay[b][k + 4 * half];
+                }
+                f8::sub(nb, num[h], b8);
+                f8::addsub<(~kSignY) & 0xFFu>(nq, nb, t8);
+                u32 U[8], V[8], W[8], Z[8];
+                const u32 P = vgpr_P();
+                f8::done();
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int r = 4 * half + (s & 3);
+                    U[s] = nq[s & 3]; W[s] = nq[4 + (s & 3)];
+                    V[s] = s < 4 ? ir[b][r] : ii[b][r];
+                    Z[s] = s < 4 ? P - ii[b][r] : ir[b][r];
+                }
+                u64 a64[8];
+                f8::boundary<kPrioHeavy>(U, V, W, Z);
+                f8::mul64(a64, U, V); f8::mad(a64, W, Z);
+                f8::reduce<false>(term[b][h], a64);
+            }
+        }
+        f8::done();
+        const qm31 coeff1 = batches[1].coeff;
+        u32 o[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const qm31 m = qm31_mul({term[0][0][r], term[0][0][4 + r], term[0][1][r], term[0][1][4 + r]}, coeff1);
+            o[0][r] = m31_add(m.a, term[1][0][r]); o[1][r] = m31_add(m.b, term[1][0][4 + r]);
+            o[2][r] = m31_add(m.c, term[1][1][r]); o[3][r] = m31_add(m.d, term[1][1][4 + r]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) gstore4(out.p[k], half ? rowB : rowA, make_uint4(o[k][0], o[k][1], o[k][2], o[k][3]));
+    }
+    if (zero) raise_flag(flag);
+}
+
 // Any log_size (used for log_size < 3): one row per lane, the reference's formulation verbatim.
 __global__ void __launch_bounds__(256) k_quotients_row(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
                                                       const BatchConst *__restrict__ batches, u32 n_batches,
@@ -371,6 +512,16 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         static const bool no_lazy = getenv("TSTWO_QUOT_NO_LAZY") != nullptr;          // (measurement knob: reduce after every group of 4)
         for (size_t b = 0; b < n_batches; b++) lazy = lazy || (!no_lazy && batch_off[b + 1] - batch_off[b] > 4);
         const dim3 grid(ceil_div(n_threads, 256));
+        // two batches over one column list (same columns in the same order): the column words are loaded once for both
+        static const bool no_pair = getenv("TSTWO_QUOT_NO_PAIR") != nullptr;          // (A/B timing)
+        bool pair = n_batches == 2 && !no_pair && batch_off[1] - batch_off[0] == batch_off[2] - batch_off[1] && batch_off[1] > batch_off[0];
+        for (size_t j = batch_off[0]; pair && j < batch_off[1]; j++) pair = col_idx[j] == col_idx[j - batch_off[0] + batch_off[1]];
+        if (pair) {
+            hipLaunchKernelGGL(k_quotients8_pair, grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, d_cols, d_b, d_e, o4, c.gen_win,
+                               qb, bsel, c.flag);
+            TSTWO_LAUNCH_CHECK();
+            return TSTWO_OK;
+        }
 #define TSTWO_QLAUNCH(S, Z) hipLaunchKernelGGL((k_quotients8<S, Z>), grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, d_cols, d_b, \
                                                (u32)n_batches, d_e, o4, c.gen_win, qb, bsel, c.flag)
         if (n_batches == 1 && lazy) TSTWO_QLAUNCH(true, true);
