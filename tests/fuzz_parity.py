@@ -206,9 +206,13 @@ def case_quotients():
     cols = [rcol(1 << n) for _ in range(n_cols)]
     n_batches = int(rng.integers(1, 4))
     batches_o, batches_t = [], []
+    shared = rng.choice(n_cols, size=int(rng.integers(1, n_cols + 1)), replace=False) if rng.integers(0, 3) == 0 else None
     for _ in range(n_batches):
         pt = _rand_secure_point()
-        cv = [(int(c), _rq()) for c in rng.choice(n_cols, size=int(rng.integers(1, n_cols + 1)), replace=False)]
+        # one time in three every batch covers the same columns in the same order (each column opened at several points: with two
+        # batches that is the shared-load kernel, k_quotients8_pair)
+        chosen = shared if shared is not None else rng.choice(n_cols, size=int(rng.integers(1, n_cols + 1)), replace=False)
+        cv = [(int(c), _rq()) for c in chosen]
         batches_o.append((pt.x.tup(), pt.y.tup(), cv))
         batches_t.append(T.ColumnSampleBatch(pt, [(c, T.QM31.from_u32_unchecked(*v)) for c, v in cv]))
     coeff = _rq()
