@@ -17,7 +17,7 @@ from .queries import Queries, get_query_positions_by_log_size
 from .fields import M31, P, QM31
 from .fri import CIRCLE_TO_LINE_FOLD_STEP, HipFriOps
 from .poly import LineEvaluation, SecureEvaluation, TwiddleTree
-from .vcs import DeviceHashLayer, HashSlices, M31Values, MerkleDecommitment, MerkleProver
+from .vcs import DeviceHashLayer, HashSlices, M31Values, MerkleDecommitment, MerkleProver, TreeLayers
 
 FOLD_STEP = 1
 
@@ -402,7 +402,7 @@ class FriProver:
 
         def tree_of(ptr, max_log):
             buf = L.DeviceBuffer.adopt(ptr, 32 * ((2 << max_log) - 1))
-            return MerkleProver([DeviceHashLayer(buf, 1 << k, 32 * ((1 << k) - 1)) for k in range(max_log + 1)], buf, None)
+            return MerkleProver(TreeLayers(buf, max_log), buf, None)
 
         def eval_of(o, domain):
             n = 1 << o.log_size
