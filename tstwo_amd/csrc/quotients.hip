@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 l
         f8::mul(ay[b], a8, yy);
     }
     const u32 begin0 = batches[0].begin, begin1 = batches[1].begin, n_entries = batches[0].end - batches[0].begin;
-#pragma unroll
+#pragma unroll 1          // (rolled on purpose: one copy of the body; ay / ir / ii are then indexed by `half` at run time — eight LDS accesses per lane)
     for (int half = 0; half < 2; half++) {
         u64 accq[2][2][8];
 #pragma unroll
