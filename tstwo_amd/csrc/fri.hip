@@ -69,6 +69,43 @@ __global__ void __launch_bounds__(256) k_fold_circle(Soa4 dst, CSoa4 src, size_t
     }
 }
 
+// Two consecutive output rows per lane: 16-byte loads of the source, 8-byte accesses of dst (log 24: 94.2 against 96.7 us for the
+// one-row form; needs 16-byte aligned source columns and 8-byte aligned dst columns, tree twiddles).  TSTWO_FOLD1 = the one-row form.
+template <bool ACCUM>
+__global__ void __launch_bounds__(256) k_fold_circle2(Soa4 dst, CSoa4 src, size_t n_out, const u32 *__restrict__ twp,
+                                                     qm31 alpha, qm31 alpha_sq, const qm31 *__restrict__ alpha_dev) {
+    if (alpha_dev) { alpha = *alpha_dev; if (ACCUM) alpha_sq = qm31_mul(alpha, alpha); }
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_out / 2; j += stride) {
+        // rows i = 2j, 2j + 1 share the twiddle twp[j ^ 1] up to sign: negative iff (i ^ (i >> 1)) & 1
+        const u32 tw = twp[j ^ 1];
+        const u32 t0 = (j & 1) ? m31_neg(tw) : tw, t1 = (j & 1) ? tw : m31_neg(tw);
+        const uint4 a = gload4(src.p[0] + 4 * j), b = gload4(src.p[1] + 4 * j), c = gload4(src.p[2] + 4 * j), d = gload4(src.p[3] + 4 * j);
+        uint2 cur[4];
+        if (ACCUM) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = gload2(dst.p[k] + 2 * j);
+        }
+        qm31 r[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const u32 ax = h ? a.z : a.x, ay = h ? a.w : a.y, bx = h ? b.z : b.x, by = h ? b.w : b.y;
+            const u32 cx = h ? c.z : c.x, cy = h ? c.w : c.y, dx = h ? d.z : d.x, dy = h ? d.w : d.y;
+            const qm31 f0 = {m31_add(ax, ay), m31_add(bx, by), m31_add(cx, cy), m31_add(dx, dy)};
+            const qm31 f1 = qm31_mul_m31({m31_sub(ax, ay), m31_sub(bx, by), m31_sub(cx, cy), m31_sub(dx, dy)}, h ? t1 : t0);
+            r[h] = qm31_add(qm31_mul(alpha, f1), f0);
+            if (ACCUM) {
+                const qm31 cu = {h ? cur[0].y : cur[0].x, h ? cur[1].y : cur[1].x, h ? cur[2].y : cur[2].x, h ? cur[3].y : cur[3].x};
+                r[h] = qm31_add(qm31_mul(cu, alpha_sq), r[h]);
+            }
+        }
+        *(TSTWO_GLOBAL u32x2_t *)(dst.p[0] + 2 * j) = u32x2_t{r[0].a, r[1].a};
+        *(TSTWO_GLOBAL u32x2_t *)(dst.p[1] + 2 * j) = u32x2_t{r[0].b, r[1].b};
+        *(TSTWO_GLOBAL u32x2_t *)(dst.p[2] + 2 * j) = u32x2_t{r[0].c, r[1].c};
+        *(TSTWO_GLOBAL u32x2_t *)(dst.p[3] + 2 * j) = u32x2_t{r[0].d, r[1].d};
+    }
+}
+
 // (A form with a lane owning 4 consecutive output rows — every access 16 bytes per lane instead of 8 / 4 — was built and
 // measured in round 3: fold_circle_into_line log 24 103.9 against 106.7 us, fold_line log 23 37.9 against 35.3 us: the
 // folds already move 5.0 - 5.9 TB/s and the 120 VGPRs of the 4-row form cost as much occupancy as the wider accesses
@@ -310,7 +347,12 @@ static void launch_fold_line(const CSoa4 &i4, const Soa4 &o4, size_t n_out, cons
     hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, alpha, alpha_dev);
 }
 static void launch_fold_circle(bool from_tree, const Soa4 &d4, const CSoa4 &s4, size_t n_out, const u32 *twp, qm31 a, qm31 a2, const qm31 *alpha_dev) {
-    if (from_tree)
+    static const bool fold1 = getenv("TSTWO_FOLD1") != nullptr;
+    bool two = from_tree && !fold1 && n_out >= 4;
+    for (int k = 0; k < 4; k++) two = two && (((uintptr_t)s4.p[k]) & 15) == 0 && (((uintptr_t)d4.p[k]) & 7) == 0;
+    if (two)
+        hipLaunchKernelGGL(k_fold_circle2<true>, dim3(capped_blocks(n_out / 2, 256)), dim3(256), 0, ctx().stream, d4, s4, n_out, twp, a, a2, alpha_dev);
+    else if (from_tree)
         hipLaunchKernelGGL(k_fold_circle<true>, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, d4, s4, n_out, twp, a, a2, alpha_dev);
     else
         hipLaunchKernelGGL(k_fold_circle<false>, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, d4, s4, n_out, twp, a, a2, alpha_dev);
@@ -520,8 +562,14 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
         const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (col_logs[0] - 1));
         Soa4 d4 = {{cur[0], cur[1], cur[2], cur[3]}};
         CSoa4 s4 = {{circle_cols[0], circle_cols[1], circle_cols[2], circle_cols[3]}};
-        hipLaunchKernelGGL((k_fold_circle<true, false>), dim3(capped_blocks((size_t)1 << cur_log, 256)), dim3(256), 0, ctx().stream, d4, s4,
-                           (size_t)1 << cur_log, seg1, qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha);
+        bool two = cur_log >= 2 && !getenv("TSTWO_FOLD1");
+        for (int k = 0; k < 4; k++) two = two && (((uintptr_t)s4.p[k]) & 15) == 0 && (((uintptr_t)d4.p[k]) & 7) == 0;
+        if (two)
+            hipLaunchKernelGGL(k_fold_circle2<false>, dim3(capped_blocks((size_t)1 << (cur_log - 1), 256)), dim3(256), 0, ctx().stream, d4, s4,
+                               (size_t)1 << cur_log, seg1, qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha);
+        else
+            hipLaunchKernelGGL((k_fold_circle<true, false>), dim3(capped_blocks((size_t)1 << cur_log, 256)), dim3(256), 0, ctx().stream, d4, s4,
+                               (size_t)1 << cur_log, seg1, qm31{0, 0, 0, 0}, qm31{0, 0, 0, 0}, (const qm31 *)alpha);
         if (hipGetLastError() != hipSuccess) return fail(set_error(TSTWO_ERR_HIP, "fri commit: fold launch failed"));
         nxt = 1;
     }
