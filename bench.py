@@ -95,6 +95,63 @@ def host_cores() -> int:
         return os.cpu_count() or 1
 
 
+def cpu_quota_cores():
+    """The CPU time this process's cgroup may use, in cores (cgroup v2 cpu.max, v1 cfs quota); None = unlimited / unknown.
+    A GPU box shows every core of the host in the affinity mask and grants a fraction of them as quota."""
+    for quota_f, period_f in (("/sys/fs/cgroup/cpu.max", None),
+                              ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            txt = open(quota_f).read().split()
+            if period_f is None:
+                quota, period = txt[0], txt[1]
+            else:
+                quota, period = txt[0], open(period_f).read().split()[0]
+            if quota in ("max", "-1"):
+                return None
+            return float(quota) / float(period)
+        except (OSError, IndexError, ValueError):
+            continue
+    return None
+
+
+def launch_ranks(n_gpus: int, argv: list) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process — which has not imported torch nor
+    touched the GPU library, and never will — starts N fresh interpreters of this file, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, a free port on 127.0.0.1), lets rank 0's stdout through (the ONE JSON line),
+    sends the other ranks' stdout to stderr, and returns non-zero if any rank does (the others are then stopped by PID)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n_gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in live:
+                    procs[o].terminate()
+                deadline = time.time() + 20
+                for o in live:
+                    try:
+                        procs[o].wait(max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        procs[o].kill()
+        time.sleep(0.05)
+    return rc
+
+
 def splitmix_columns(seeds, n: int) -> list:
     """The same columns, generated on a few host threads (numpy releases the GIL): 256 columns x 2^22 take ~0.4 s each on one."""
     from concurrent.futures import ThreadPoolExecutor
@@ -112,9 +169,12 @@ def cpu_oracle():
 def cpu_baseline(cols_host: list, n: int, tree_cols: int, single_cols: int, threads: int = 0):
     """CPU oracle (oracle/, kind "port": -O3 scalar C) timed beside the GPU step:
       * one thread: `single_cols` of the columns — CFFT evaluate + Merkle commit over them;
-      * all host cores (reported as cpu_baseline.value): the FULL step of rank 0 at N = 1 — every column of the trace — on C
-        threads (oracle/tstwo_oracle_mt.c: one column per task for the CFFT; per tree the leaf range cut into contiguous
-        shards, whose root equals the single-tree root) — `threads` = every core the process may run on unless given.
+      * a thread sweep on a bounded sample (CFFT of up to 32 of the columns, copies): 8, 16, ... up to every core in the
+        affinity mask, plus the cgroup's CPU quota when it has one — a GPU box shows all of the host's cores in the mask and
+        grants a fraction of them, so "every core" oversubscribes; the fastest count is the one the full step then runs on;
+      * the FULL step of the trace — every column, every tree — on that many C threads (oracle/tstwo_oracle_mt.c: one column
+        per task for the CFFT; per tree the leaf range cut into contiguous shards, whose root equals the single-tree root):
+        reported as cpu_baseline.value with cores = the threads used, `affinity_cores` and `cpu_quota_cores` beside it.
     `cols_host` (the step's input, host copies) is transformed IN PLACE.  Returns the record; its "roots" are the oracle's
     roots of the step's trees, which main() compares with the GPU's."""
     orc = cpu_oracle()
@@ -133,8 +193,20 @@ def cpu_baseline(cols_host: list, n: int, tree_cols: int, single_cols: int, thre
     }
     del evs
     cores = host_cores()
+    quota = cpu_quota_cores()
+    sweep = {}
     if threads <= 0:
-        threads = cores
+        cand = {c for c in (8, 16, 32, 64, 128, 256, 512) if c < cores} | {cores}
+        if quota:
+            cand.add(max(1, min(cores, int(round(quota)))))
+        sample = [c.copy() for c in cols_host[:min(32, n_cols)]]
+        for t in sorted(cand):
+            work = [c.copy() for c in sample]
+            ts = time.perf_counter()
+            orc.mt_cfft_evaluate(work, n, half, tw, n - 1, t)
+            sweep[t] = len(work) * (1 << n) / (time.perf_counter() - ts)
+        del sample, work
+        threads = max(sweep, key=sweep.get)
     t3 = time.perf_counter()
     orc.mt_cfft_evaluate(cols_host, n, half, tw, n - 1, threads)       # in place
     t4 = time.perf_counter()
@@ -144,10 +216,14 @@ def cpu_baseline(cols_host: list, n: int, tree_cols: int, single_cols: int, thre
         "value": n_cols * (1 << n) / (t5 - t3),
         "unit": "elems/s",
         "cores": threads,
+        "affinity_cores": cores,
+        "cpu_quota_cores": quota,
         "kind": "port",
-        "sample": f"the full step ({n_cols} columns x 2^{n}, {len(roots)} trees of {tree_cols} columns) on {threads} C threads = every core "
-                  f"this process may use (os.cpu_count() = {os.cpu_count()}): column-parallel CFFT ({t4 - t3:.2f} s) + leaf-sharded "
+        "sample": f"the full step ({n_cols} columns x 2^{n}, {len(roots)} trees of {tree_cols} columns) on {threads} C threads — the fastest "
+                  f"of a sweep over {sorted(sweep) if sweep else [threads]} threads on a {min(32, n_cols)}-column CFFT sample (affinity mask {cores} "
+                  f"cores, cgroup CPU quota {quota if quota else 'none'}): column-parallel CFFT ({t4 - t3:.2f} s) + leaf-sharded "
                   f"Merkle commits ({t5 - t4:.2f} s); oracle built -O3",
+        "thread_sweep_cfft_elems_per_s": {str(k): v for k, v in sorted(sweep.items())},
         "cfft_butterflies_per_s": n_cols * n * (1 << (n - 1)) / (t4 - t3),
         "roots": [r.hex() for r in roots],
         "single_thread": single,
@@ -212,9 +288,16 @@ def main():
     ap.add_argument("--pmc-json", default=None, help="tools/pmc_summary.py output of an earlier --pmc run of THIS build, instead of the child passes")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this process: be the launcher (nothing above imported torch or the GPU library)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a line for another N")
     n, tree_cols = args.log_size, args.tree_cols
     N = 1 << n
     total_cols = args.total_cols if args.scaling == "strong" else args.cols * world
@@ -222,9 +305,11 @@ def main():
         raise SystemExit(f"bench.py: {total_cols} columns do not split into {tree_cols}-column trees over {world} GPUs")
 
     # ---- HBM counters of the launches this run times, from a child process, before this one touches the GPU (N = 1 only)
-    traffic, traffic_source = None, {"reason": "not collected (N > 1, --no-pmc or not rank 0)"}
-    if rank == 0 and world == 1 and not args.no_pmc and not args.pmc_json:
-        traffic, traffic_source = pmc_traffic(n, total_cols)
+    # (N > 1: rank 0 collects them for ITS shard's launch shape before the rendezvous; the other ranks wait there and have not
+    # touched a GPU either)
+    traffic, traffic_source = None, {"reason": "not collected (--no-pmc or not rank 0)"}
+    if rank == 0 and not args.no_pmc and not args.pmc_json:
+        traffic, traffic_source = pmc_traffic(n, total_cols // world)
 
     # torch.distributed is control plane only (rendezvous, barrier, max-reduce of the elapsed time, hand-over of the RCCL
     # unique id) on the gloo backend; the one collective on the data path — the all-gather of Merkle roots — is RCCL
@@ -249,7 +334,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
 
     from tstwo_amd import _lib as L
     from tstwo_amd.backend import HipBackend, shard_columns
@@ -269,7 +355,7 @@ def main():
     my_cols = shard_columns(total_cols, world, rank)
     n_cols = len(my_cols)
     n_trees = n_cols // tree_cols
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu
+    want_cpu = rank == 0 and not args.no_cpu          # the oracle leg: the WHOLE trace on rank 0's host cores, whatever N is
     cols_host = splitmix_columns([100 + c for c in my_cols], N)
     dev_cols = []
     L.sync()
@@ -470,8 +556,17 @@ def main():
             "device": L.device_name(),
         }
         root_ok = None
-        if want_cpu:                                   # rank 0 at N = 1 only
+        if want_cpu:
+            # rank 0, every N: the oracle transforms and commits the WHOLE fixed trace (at N > 1 the other ranks' columns are
+            # generated here from their seeds), so cpu_baseline is the N = 1 figure of this box and its roots check all the
+            # first-step roots the ranks all-gathered — the TreeVec's roots do not depend on N (pcs/prover.ts:62-64,227-228)
             del dev_cols[:], layers[:]
+            if world > 1:
+                all_cols = [c for r in range(world) for c in shard_columns(total_cols, world, r)]
+                mine = dict(zip(my_cols, cols_host))
+                others = [c for c in all_cols if c not in mine]
+                mine.update(zip(others, splitmix_columns([100 + c for c in others], N)))
+                cols_host = [mine[c] for c in all_cols]
             out["cpu_baseline"] = cpu_baseline(cols_host, n, tree_cols, min(args.cpu_cols, n_cols))
             root_ok = "".join(out["cpu_baseline"]["roots"]) == tree_roots_first.hex()
             cols_host = None

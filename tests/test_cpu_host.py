@@ -494,3 +494,78 @@ def test_bit_reverse_perm_matches_bit_reverse_index():
     for lg in range(0, 11):
         assert bit_reverse_perm(lg).tolist() == [bit_reverse_index(i, lg) for i in range(1 << lg)]
     assert not bit_reverse_perm(5).flags.writeable
+
+
+def test_bench_refuses_a_gpu_count_that_is_not_the_world_size():
+    """bench.py --gpus N under a launcher that started another number of ranks must fail, never print a line for another N
+    (round 3 parsed --gpus and ignored it).  The check runs before anything imports torch or touches the GPU library."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr and p.stdout.strip() == ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "0"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+
+
+def test_bench_launcher_relays_rank_failure(tmp_path):
+    """launch_ranks: N fresh interpreters with RANK / WORLD_SIZE / MASTER_* set, rank 0's stdout passed through, a failing rank
+    turns into a non-zero exit and stops the others."""
+    import subprocess
+    import textwrap
+    sys.path.insert(0, ROOT)
+    script = tmp_path / "launch.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys, time
+        sys.path.insert(0, {ROOT!r})
+        if "WORLD_SIZE" in os.environ:                      # a rank
+            r = int(os.environ["RANK"])
+            assert os.environ["WORLD_SIZE"] == "3" and os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+            print("line from rank", r, flush=True)
+            if sys.argv[1] == "fail" and r == 1:
+                sys.exit(7)
+            if sys.argv[1] == "fail":
+                time.sleep(60)                                # must be stopped by the launcher, not waited for
+            sys.exit(0)
+        import bench
+        bench.__file__ = {str(script)!r}
+        sys.exit(bench.launch_ranks(3, sys.argv[1:]))
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, str(script), "ok"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0 and p.stdout.strip() == "line from rank 0"
+    assert "line from rank 1" in p.stderr and "line from rank 2" in p.stderr
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(script), "fail"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 7 and time.time() - t0 < 40 and "rank 1 exited with 7" in p.stderr
+
+
+def test_shipped_library_has_no_experiment_switches():
+    """The drop-in .so must not change results or kernel plans because of its caller's environment (round 3: 36 TSTWO_* variables,
+    one of which skipped a CFFT pass).  The shipped build keeps the loader / allocator variables and nothing else; the tuning and
+    A/B switches exist only in the experiments build (-DTSTWO_EXPERIMENTS), where they are read once."""
+    import re
+    from tstwo_amd import _lib as L
+    allowed = {"TSTWO_ALLOC", "TSTWO_NO_POOL", "TSTWO_POISON", "TSTWO_ALLOW_UNSAFE_ASYNC_ALLOC", "TSTWO_ASYNC_RELEASE", "TSTWO_RCCL_LIB"}
+    names = lambda path: set(m.decode() for m in re.findall(rb"TSTWO_[A-Z0-9_]+", open(path, "rb").read()))
+    shipped = {n for n in names(L.LIB_PATH) if not n.startswith(("TSTWO_ERR_", "TSTWO_ALLOC_"))}
+    assert shipped <= allowed, sorted(shipped - allowed)
+    if os.path.exists(L.LIB_EXP_PATH):
+        assert {"TSTWO_CFFT_GENERIC", "TSTWO_MERKLE_SUBTREE", "TSTWO_FRI_NO_TAIL"} <= names(L.LIB_EXP_PATH)
+    # and in the sources: no getenv outside context.hip's allocator / comm.hip's loader and the #ifdef TSTWO_EXPERIMENTS block
+    csrc = os.path.join(ROOT, "tstwo_amd", "csrc")
+    outside = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".cuh", ".h")):
+            continue
+        depth = 0
+        for line in open(os.path.join(csrc, f)):
+            t = line.strip()
+            if t.startswith("#ifdef TSTWO_EXPERIMENTS"):
+                depth += 1
+            elif depth and t.startswith(("#else", "#endif")):
+                depth -= 1
+            elif not depth and "getenv(" in line and not t.startswith("//"):
+                assert f in ("context.hip", "comm.hip"), (f, line)
+                outside += 1
+    assert outside <= 8, outside

@@ -1324,6 +1324,82 @@ class _RawQueries:
         self.positions, self.log_domain_size = positions, log_domain_size
 
 
+def _fri_commit_digest(prover, ch):
+    """Everything a commit produced, hashed: channel state, every tree's root, every layer's evaluation, the last-layer polynomial."""
+    import hashlib
+    h = hashlib.blake2s()
+    h.update(ch.digest())
+    h.update(prover.first_layer.merkle_tree.root())
+    for la in prover.inner_layers:
+        h.update(la.merkle_tree.root())
+        for c in la.evaluation.values.to_numpy():
+            h.update(c.tobytes())
+    for c in prover.last_layer_poly.coeffs:
+        h.update(np.array(c.tup(), dtype="<u4").tobytes())
+    return h.hexdigest()
+
+
+_FRI_BIG_CASES = {"single19": ([17], 2, (3, 2, 12)), "mixed19": ([17, 15, 12], 2, (4, 2, 10)), "single18b1": ([17], 1, (2, 1, 8))}
+_FRI_BIG_SCRIPT = r"""
+import sys
+sys.path[:0] = [{root!r}, {tests!r}]
+import tstwo_amd as T
+from tstwo_amd import _lib as L
+from test_gpu_backend import _FRI_BIG_CASES, _fri_commit_digest, _secure_low_degree_eval
+for name, (log_degs, blow, cfg) in _FRI_BIG_CASES.items():
+    cols = [_secure_low_degree_eval(ld, blow, 8300 + ld)[0] for ld in log_degs]
+    tw = _secure_low_degree_eval(log_degs[0], blow, 8300 + log_degs[0])[1]
+    ch = T.Blake2sChannel()
+    print(L.version().replace(" ", "_"), name, _fri_commit_digest(T.FriProver.commit(ch, T.FriConfig(*cfg), cols, tw), ch))
+"""
+
+
+def test_fri_commit_layers_big_layers_match_host_loop_and_verify(monkeypatch):
+    """The prover-critical branches of tstwo_fri_commit_layers above 2^16 rows — fold fused into k_merkle_leaf4<true> through
+    commit_layer (grid-strided, deferred digest stores), k_fold_circle2 with a capped grid, commit_upper_levels starting with
+    1024-lane workgroups, k_channel_mix_draw when the hook is left set — ran only in timing tools.  Circle log 18-19, one column
+    and mixed sizes (a column entering at a line layer of 2^16 and one at 2^13 rows): the library loop against round 2's
+    per-layer host loop (every root, every evaluation, last-layer coefficients, channel state), then decommit + verify; and the
+    same commits in the experiments build with the fusion / the single-launch tail switched off (the unfused and spare-tree
+    branches), which must give the same bytes."""
+    import os
+    import subprocess
+    import sys
+    want = {}
+    for name, (log_degs, blow, cfgt) in _FRI_BIG_CASES.items():
+        cfg = T.FriConfig(*cfgt)
+        cols = [_secure_low_degree_eval(ld, blow, 8300 + ld)[0] for ld in log_degs]
+        tw = _secure_low_degree_eval(log_degs[0], blow, 8300 + log_degs[0])[1]
+        ch_a, ch_b = T.Blake2sChannel(), T.Blake2sChannel()
+        a = T.FriProver.commit(ch_a, cfg, cols, tw)
+        monkeypatch.setenv("TSTWO_FRI_COMMIT_HOST_LOOP", "1")
+        b = T.FriProver.commit(ch_b, cfg, cols, tw)
+        monkeypatch.delenv("TSTWO_FRI_COMMIT_HOST_LOOP")
+        assert len(a.inner_layers) == len(b.inner_layers) == (log_degs[0] + blow - 1) - (cfgt[0] + blow)
+        assert a.first_layer.merkle_tree.root() == b.first_layer.merkle_tree.root()
+        for la, lb in zip(a.inner_layers, b.inner_layers):
+            assert la.merkle_tree.root() == lb.merkle_tree.root()
+            for ca, cb in zip(la.evaluation.values.to_numpy(), lb.evaluation.values.to_numpy()):
+                assert (ca == cb).all()
+        assert [c.tup() for c in a.last_layer_poly.coeffs] == [c.tup() for c in b.last_layer_poly.coeffs]
+        assert ch_a.digest() == ch_b.digest()
+        want[name] = _fri_commit_digest(a, ch_a)
+        assert want[name] == _fri_commit_digest(b, ch_b)
+        proof, positions = a.decommit(ch_a)
+        _fri_verify(cfg, proof, log_degs, _query_evals(cols, positions), positions)
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    script = _FRI_BIG_SCRIPT.format(root=os.path.dirname(tests_dir), tests=tests_dir)
+    for knobs in ({"TSTWO_FRI_NO_FOLD_FUSION": "1"}, {"TSTWO_FRI_NO_TAIL": "1"}, {"TSTWO_FRI_NO_FOLD_FUSION": "1", "TSTWO_FRI_NO_TAIL": "1"}):
+        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, TSTWO_HIP_LIB=L.LIB_EXP_PATH, **knobs), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = {}
+        for line in out.stdout.strip().splitlines()[-len(want):]:
+            ver, name, digest = line.split()
+            assert "experiments" in ver
+            got[name] = digest
+        assert got == want, knobs
+
+
 def test_fri_commit_layers_capi_matches_host_loop_and_reports_errors(monkeypatch):
     """tstwo_fri_commit_layers (the whole commit loop in one call) against the per-layer calls of round 2 (same device
     transcript): identical trees, evaluations, last-layer polynomial and channel state, for one and for mixed-size columns; bad

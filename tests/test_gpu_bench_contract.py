@@ -48,3 +48,20 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--no-cpu"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert one.returncode == 0, one.stderr[-2000:]
     assert _line(one.stdout)["gpu_roots"] == d["gpu_roots"]         # the TreeVec's roots do not depend on the GPU count
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_checks_every_root():
+    """`python bench.py --gpus 2` with no launcher around it — the form the driver uses — must start two ranks itself, print
+    n_gpus 2 and check the all-gathered first-step roots of BOTH ranks against the oracle (root_match), with a cpu_baseline."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TSTWO_BENCH_COLLECTIVE"] = "gloo"               # one GPU here: both ranks share it, roots travel through the host
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["columns_per_gpu"] == 32 and d["config"]["parallelism"] == "column-shard x2"
+    assert d["root_match"] is True and len(d["gpu_roots"]) == 2
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["roots"] == d["gpu_roots"] and c["cores"] >= 1
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--no-cpu"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    assert _line(one.stdout)["gpu_roots"] == d["gpu_roots"]         # the same trees whatever N is

@@ -411,8 +411,8 @@ print(bytes(root).hex(), hashlib.blake2s(b"".join(l.tobytes() for l in layers)).
 
 @pytest.mark.parametrize("levels", ["0", "3", "4"])
 def test_merkle_subtree_levels_agree(levels):
-    """TSTWO_MERKLE_SUBTREE is read once per process: every setting (layer per launch, 3 and 4 layers per in-lane subtree;
-    2 is the default the other tests run) must give the oracle's tree."""
+    """TSTWO_MERKLE_SUBTREE (experiments build only; read once per process): every setting (layer per launch, 3 and 4 layers per
+    in-lane subtree; 2 is the default the other tests run) must give the oracle's tree."""
     import os
     import subprocess
     import sys
@@ -422,7 +422,7 @@ def test_merkle_subtree_levels_agree(levels):
     want = bytes(oroot).hex() + " " + hashlib.blake2s(b"".join(l.tobytes() for l in olayers)).hexdigest()
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     script = _SUBTREE_SCRIPT.format(root=os.path.dirname(tests_dir), tests=tests_dir)
-    env = dict(os.environ, TSTWO_MERKLE_SUBTREE=levels)
+    env = dict(os.environ, TSTWO_MERKLE_SUBTREE=levels, TSTWO_HIP_LIB=L.LIB_EXP_PATH)
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == want
@@ -862,6 +862,81 @@ def test_host_array_upload_during_graph_capture_is_refused():
     L.call("tstwo_cfft_evaluate", ptrs(evs), len(evs), 13, half_odds(12), vp(tw), 12)
     for i in (0, 1, 69):
         assert (host(evs[i], 1 << 13) == orc.cfft_evaluate(evs_host[i], 13, half_odds(12), otw, 12)).all()
+
+
+def test_device_pointer_table_is_refused_during_capture_on_a_cache_hit_too():
+    """The pointer table of a > 64-column call lives in a slot of device memory that the NEXT such call rewrites.  Round 3 refused
+    only the upload (a cache miss); on a hit — the same call made eagerly just before — the launch was recorded against the slot
+    with no refusal, and a later call would have changed what the graph reads at replay.  Eager call, then the same call under
+    capture: error; and the eager call still works afterwards."""
+    evs_host = [rand_column(1990 + i, 1 << 13) for i in range(70)]
+    evs = [dev(e) for e in evs_host]
+    tw = dev_empty(1 << 12)
+    L.call("tstwo_twiddles_build", half_odds(12), 12, vp(tw), vp(None))
+    table = ptrs(evs)
+    L.call("tstwo_cfft_evaluate", table, len(evs), 13, half_odds(12), vp(tw), 12)        # fills the slot: the next call is a hit
+    L.sync()
+    L.call("tstwo_graph_begin_capture")
+    try:
+        with pytest.raises(L.TstwoError, match="during graph capture"):
+            L.call("tstwo_cfft_evaluate", table, len(evs), 13, half_odds(12), vp(tw), 12)
+    finally:
+        h = C.c_void_p()
+        try:
+            L.call("tstwo_graph_end_capture", C.byref(h))
+        except L.TstwoError:
+            pass
+        if h.value:
+            L.call("tstwo_graph_destroy", h)
+    itw = dev_empty(1 << 12)
+    L.call("tstwo_twiddles_build", half_odds(12), 12, vp(None), vp(itw))
+    L.call("tstwo_cfft_interpolate", table, len(evs), 13, half_odds(12), vp(itw), 12)
+    for i in (0, 33, 69):
+        assert (host(evs[i], 1 << 13) == evs_host[i]).all()
+
+
+_KNOB_SCRIPT = r"""
+import sys
+sys.path[:0] = [{root!r}, {tests!r}]
+import numpy as np
+from test_gpu_capi import rand_column, dev, dev_empty, host, ptrs, half_odds, vp, L
+n = 15
+cols = [dev(rand_column(4200 + c, 1 << n)) for c in range(3)]
+tw = dev_empty(1 << (n - 1))
+L.call("tstwo_twiddles_build", half_odds(n - 1), n - 1, vp(tw), vp(None))
+L.call("tstwo_cfft_evaluate", ptrs(cols), 3, n, half_odds(n - 1), vp(tw), n - 1)
+import hashlib
+print(L.version(), hashlib.blake2s(b"".join(host(c, 1 << n).tobytes() for c in cols)).hexdigest())
+"""
+
+
+def test_shipped_library_ignores_the_experiment_knobs():
+    """TSTWO_CFFT_GENERIC=4 SKIPS the bottom pass — in the experiments build.  The shipped library must not let its caller's
+    environment change a result: with the variable set it still gives the oracle's evaluations, while the experiments build,
+    given the same variable, demonstrably does not (so the test would notice if the switch stopped meaning anything)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    n = 15
+    otw = orc.precompute_twiddles(half_odds(n - 1), n - 1)[0]
+    want = hashlib.blake2s(b"".join(orc.cfft_evaluate(rand_column(4200 + c, 1 << n), n, half_odds(n - 1), otw, n - 1).tobytes()
+                                    for c in range(3))).hexdigest()
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    script = _KNOB_SCRIPT.format(root=os.path.dirname(tests_dir), tests=tests_dir)
+    knobs = dict(TSTWO_CFFT_GENERIC="4", TSTWO_CFFT_KB="12", TSTWO_MERKLE_GENERIC="1", TSTWO_CFFT_ROUNDS="3")
+    env = {k: v for k, v in os.environ.items() if k != "TSTWO_HIP_LIB"}
+    out = subprocess.run([sys.executable, "-c", script], env=dict(env, **knobs), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ver, digest = out.stdout.strip().splitlines()[-1].rsplit(" ", 1)
+    assert "experiments" not in ver and digest == want
+    out = subprocess.run([sys.executable, "-c", script], env=dict(env, TSTWO_HIP_LIB=L.LIB_EXP_PATH, **knobs), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    ver, digest = out.stdout.strip().splitlines()[-1].rsplit(" ", 1)
+    assert "experiments" in ver and digest != want
+    out = subprocess.run([sys.executable, "-c", script], env=dict(env, TSTWO_HIP_LIB=L.LIB_EXP_PATH, TSTWO_CFFT_KB="12"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1].rsplit(" ", 1)[1] == want          # a plan-changing knob alone: same results
 
 
 @pytest.mark.parametrize("shape", [(4, 32, 17), (8, 32, 18), (3, 16, 19), (2, 64, 17), (5, 48, 17), (2, 32, 12), (1, 32, 17), (3, 20, 17)], ids=str)

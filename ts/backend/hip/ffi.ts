@@ -119,6 +119,12 @@ export class DeviceBuffer {
     check(hip.tstwo_malloc(ptr(out), BigInt(Math.max(nbytes, 16))));
     this.dev = out[0]!;
   }
+  /** Take ownership of a block the LIBRARY allocated with tstwo_malloc and handed out (tstwo_fri_commit_layers). */
+  static adopt(dev: bigint, nbytes: number): DeviceBuffer {
+    const b = Object.create(DeviceBuffer.prototype) as { dev: bigint; nbytes: number };
+    b.dev = dev; b.nbytes = nbytes;
+    return b as DeviceBuffer;
+  }
   upload(words: Uint32Array | Uint8Array, byteOffset = 0): void {
     if (words.byteLength) check(hip.tstwo_upload(this.dev + BigInt(byteOffset), ptr(words), BigInt(words.byteLength)));
   }

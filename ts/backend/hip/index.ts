@@ -317,6 +317,8 @@ export class HipMerkleOps implements MerkleOps<Blake2sHash> {
  *  class, like MerkleProver.commit's stable sort. */
 export class HipMerkleProver {
   private constructor(readonly layers: DeviceBuffer, readonly maxLog: number, private readonly rootBytes: Uint8Array) {}
+  /** A tree the library built and handed out (tstwo_fri_commit_layers): `layers` in tstwo_merkle_commit's layout, root first. */
+  static adopt(layers: DeviceBuffer, maxLog: number): HipMerkleProver { return new HipMerkleProver(layers, maxLog, layers.downloadBytes(32)); }
   static commit(columns: readonly HipColumn[]): HipMerkleProver {
     const logs = columns.map((c) => {
       const lg = Math.log2(c.len());
@@ -396,11 +398,23 @@ export function friDecommit(layers: readonly HipFriLayer[], queries: readonly nu
     totalEvals += l.evaluations.length;
     capH += 4 * nq * (l.tree.maxLog + 1);
   });
-  const capE = Math.max(1, 2 * nq * totalEvals), capW = Math.max(1, 8 * nq * totalEvals);
-  const evals = new Uint32Array(4 * capE), hashes = new Uint8Array(32 * capH), colWit = new Uint32Array(capW), roots = new Uint8Array(32 * n);
-  const counts = new BigUint64Array(3 * n), totals = BigUint64Array.from([BigInt(capE), BigInt(capH), BigInt(capW)]);
-  check(hip.tstwo_fri_decommit(ptr(desc), BigInt(n), ptr(BigUint64Array.from(queries.map(BigInt))), BigInt(nq), logDomainSize, firstFoldStep, foldStep,
-    ptr(evals), ptr(hashes), ptr(colWit), ptr(roots), ptr(counts), ptr(totals)));
+  let capE = Math.max(1, 2 * nq * totalEvals), capW = Math.max(1, 8 * nq * totalEvals);
+  const roots = new Uint8Array(32 * n), counts = new BigUint64Array(3 * n);
+  const qs = BigUint64Array.from(nq ? queries.map(BigInt) : [0n]);       // (ptr() of an empty typed array is not a valid address)
+  let evals!: Uint32Array, hashes!: Uint8Array, colWit!: Uint32Array;
+  // The capacities above are estimates: a first layer with several column sizes and sparse queries can exceed them.  The library
+  // then fails with "output buffer too small" and leaves the EXACT totals behind — reallocate from them and call once more
+  // (what tstwo_amd/fri_prover.py does).
+  for (let attempt = 0; ; attempt++) {
+    evals = new Uint32Array(4 * capE); hashes = new Uint8Array(32 * capH); colWit = new Uint32Array(capW);
+    const totals = BigUint64Array.from([BigInt(capE), BigInt(capH), BigInt(capW)]);
+    const rc = hip.tstwo_fri_decommit(ptr(desc), BigInt(n), ptr(qs), BigInt(nq), logDomainSize, firstFoldStep, foldStep,
+      ptr(evals), ptr(hashes), ptr(colWit), ptr(roots), ptr(counts), ptr(totals));
+    if (rc === 0) break;
+    const msg = String(hip.tstwo_last_error());
+    if (attempt > 0 || !msg.includes("output buffer too small")) throw new Error(msg);
+    capE = Math.max(1, Number(totals[0])); capH = Math.max(1, Number(totals[1])); capW = Math.max(1, Number(totals[2]));
+  }
   const out: HipFriLayerProof[] = [];
   let e0 = 0, h0 = 0, w0 = 0;
   for (let r = 0; r < n; r++) {
@@ -414,6 +428,35 @@ export function friDecommit(layers: readonly HipFriLayer[], queries: readonly nu
     e0 += ne; h0 += nh; w0 += nw;
   }
   return out;
+}
+
+/** One layer tstwo_fri_commit_layers produced: its line evaluation (4 coordinate columns of 2^logSize rows) and the tree over it
+ *  (null for the last layer, which is interpolated, not committed). */
+export interface HipFriCommittedLayer { logSize: number; columns: HipSecureColumn; tree: HipMerkleProver | null; }
+/** FriProver.commit's layer loop (commitInnerLayers, fri.ts:676-716) in ONE library call: the first layer's tree over every
+ *  circle evaluation's coordinate columns, then per layer mix_root / draw_felt on the device channel `chan` (10 words of device
+ *  memory: upload the host channel's state before, download it after), fold, commit.  `circleEvals` in decreasing size;
+ *  `alphas` receives the drawn challenges (16 bytes each).  Every buffer returned was allocated by the library (tstwo_malloc)
+ *  and is owned by the returned objects. */
+export function friCommitLayers(circleEvals: readonly HipSecureColumn[], itwiddles: HipColumn, twLog: number, logLastLayerSize: number,
+                                chan: DeviceBuffer, alphas: DeviceBuffer): { firstTree: HipMerkleProver; layers: HipFriCommittedLayer[] } {
+  const logs = circleEvals.map((e) => Math.log2(e.len()));
+  const firstLog = logs[0]! - 1;
+  if (firstLog < logLastLayerSize) throw new Error("last layer domain size mismatch");
+  const cap = firstLog - logLastLayerSize + 1;
+  const outs = new BigUint64Array(6 * cap);        // packed tstwo_fri_layer_out: { u32 log_size (+ pad); u32 *cols[4]; u8 *layers }
+  const first = new BigUint64Array(1), nOut = new BigUint64Array(1);
+  const cols = ptrs(circleEvals.flatMap((e) => e.columns.map((c) => c.dev))), lg = u32s(logs);
+  check(hip.tstwo_fri_commit_layers(ptr(cols), ptr(lg), BigInt(circleEvals.length), itwiddles.dev, twLog, logLastLayerSize, chan.dev,
+    alphas.dev, BigInt(Math.floor(alphas.nbytes / 16)), ptr(first), ptr(outs), BigInt(cap), ptr(nOut)));
+  const layers: HipFriCommittedLayer[] = [];
+  for (let i = 0; i < Number(nOut[0]); i++) {
+    const logSize = Number(outs[6 * i]! & 0xffffffffn), n = 2 ** logSize;
+    const columns = new HipSecureColumn([1, 2, 3, 4].map((k) => new HipColumn(DeviceBuffer.adopt(outs[6 * i + k]!, 4 * n), n)) as [HipColumn, HipColumn, HipColumn, HipColumn]);
+    const treeDev = outs[6 * i + 5]!;
+    layers.push({ logSize, columns, tree: treeDev ? HipMerkleProver.adopt(DeviceBuffer.adopt(treeDev, 32 * ((2 << logSize) - 1)), logSize) : null });
+  }
+  return { firstTree: HipMerkleProver.adopt(DeviceBuffer.adopt(first[0]!, 32 * ((2 << logs[0]!) - 1)), logs[0]!), layers };
 }
 
 /** The one exchange of a column-sharded prover (SURVEY.md 8e; include/tstwo_hip.h "multi-GPU"): one Bun process per GPU,

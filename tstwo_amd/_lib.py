@@ -12,6 +12,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSTWO_HIP_LIB") or os.path.join(HERE, "libtstwo_hip.so")
+# The experiments build (python -m tstwo_amd.build --experiments): the same library with DESIGN §8's TSTWO_* tuning / A-B switches
+# read from the environment.  Never loaded by default — tools/ and the tests that pin a non-default branch put it in TSTWO_HIP_LIB.
+LIB_EXP_PATH = os.path.join(HERE, "libtstwo_hip_exp.so")
 P = 2147483647
 
 
@@ -194,6 +197,11 @@ def init(device: int | None = None) -> None:
 def ensure_init() -> None:
     if not _initialised:
         init()
+
+
+def version() -> str:
+    """tstwo_version(): "... +experiments" for the experiments build."""
+    return lib().tstwo_version().decode()
 
 
 def device_count() -> int:

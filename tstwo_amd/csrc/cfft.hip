@@ -438,9 +438,8 @@ unsigned plan_grid(const void *kernel, int threads, size_t lds_bytes, size_t tot
         it = resident.emplace(kernel, per_cu).first;
     }
     size_t slots = (size_t)ctx().n_cus * (size_t)it->second;
-    static const int rounds = [] { const char *e = getenv("TSTWO_CFFT_ROUNDS"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-    slots *= (size_t)rounds;
-    static const int cap = [] { const char *e = getenv("TSTWO_CFFT_MAXWG"); return e && atoi(e) > 0 ? atoi(e) : 0; }();   // experiments
+    slots *= (size_t)knobs().cfft_rounds;
+    const int cap = knobs().cfft_maxwg;      // experiments
     if (cap && slots > (size_t)cap) slots = (size_t)cap;
     return (unsigned)(total_items < slots ? total_items : slots);
 }
@@ -457,12 +456,9 @@ template <typename KernelT, typename... Args>
 int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t tiles, u32 *const *cols, size_t n_cols, Args... args) {
     // kernel signature: (ColPtrs cols, NoSrc, n_cols, total_items, args...)
     Context &c = ctx();
-    {   // experiments: extra (unused) dynamic LDS per workgroup lowers the number of resident workgroups per CU
-        static const int pad = [] { const char *e = getenv("TSTWO_CFFT_LDS_PAD"); return e ? atoi(e) : 0; }();
-        lds_bytes += (size_t)pad;
-    }
+    lds_bytes += (size_t)knobs().cfft_lds_pad;     // experiments: extra (unused) dynamic LDS per workgroup lowers the resident workgroups per CU
     { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
-    if (getenv("TSTWO_CFFT_TRACE")) {
+    if (knobs().cfft_trace) {
         hipFuncAttributes fa;
         hipError_t e = hipFuncGetAttributes(&fa, (const void *)kernel);
         fprintf(stderr, "[cfft] kernel %p threads %d lds %zu: getattr=%d maxDynamicSharedSizeBytes=%d sharedSizeBytes=%zu numRegs=%d maxThreadsPerBlock=%d\n",
@@ -479,7 +475,7 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, c.stream, cp, fast::NoSrc{}, (u32)cnt, (u32)items, args...);
     }
     TSTWO_LAUNCH_CHECK();
-    if (getenv("TSTWO_CFFT_SYNC")) TSTWO_HIP(hipStreamSynchronize(c.stream));
+    if (knobs().cfft_sync) TSTWO_HIP(hipStreamSynchronize(c.stream));
     return TSTWO_OK;
 }
 
@@ -609,13 +605,11 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     if (tw_log > 31 || ((size_t)1 << (n - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     Pass passes[8];
     u32 kb = default_bottom_log(n), ka_max = kMaxKA;
-    {   // tuning knobs (experiments): bottom-pass size 11..14, strided-pass limit 1..10
-        const char *e1 = getenv("TSTWO_CFFT_KB"), *e2 = getenv("TSTWO_CFFT_KA");
-        if (e1 && atoi(e1) >= 11 && atoi(e1) <= 14) kb = (u32)atoi(e1);
-        if (e2 && atoi(e2) >= 1 && atoi(e2) <= 10) ka_max = (u32)atoi(e2);
-    }
+    const Knobs &kn = knobs();
+    if (kn.cfft_kb) kb = (u32)kn.cfft_kb;           // experiments build only: bottom-pass size, strided-pass limit
+    if (kn.cfft_ka) ka_max = (u32)kn.cfft_ka;
     u32 logta = kLogTileA;
-    if (n > kb && n >= kLogTileA && !getenv("TSTWO_CFFT_KB") && !getenv("TSTWO_CFFT_KA")) {     // n = 13 (and 14) is one bottom pass whatever the column count
+    if (n > kb && n >= kLogTileA && !kn.cfft_kb && !kn.cfft_ka) {     // n = 13 (and 14) is one bottom pass whatever the column count
         // Few columns: the default tiles (2^13 contiguous, 2^14 strided) give 2^(n-13) x cols and 2^(n-14) x cols workgroups;
         // below ~2 per CU pick the split with the most workgroups in its emptier pass (ties: the larger tiles).
         // n = 20, one column: 12 + 8 layers on 2^12-word tiles = 256 + 256 workgroups instead of 128 + 64.
@@ -634,23 +628,19 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
             }
         }
     }
-    if (const char *e = getenv("TSTWO_CFFT_LOGTA")) { if (atoi(e) >= 12 && atoi(e) <= 14) logta = (u32)atoi(e); }   // experiments
+    if (kn.cfft_logta) logta = (u32)kn.cfft_logta;   // experiments
     int np = n >= kMaxLogTileB ? plan_passes(n, passes, kb, ka_max, logta) : plan_passes(n, passes);
     for (size_t i = 0; i < n_cols; i++)
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
     if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
     const u32 *tw_end = tw + ((size_t)1 << tw_log);
     const bool fast_path = n >= kMaxLogTileB && n <= kMaxLogSize;
-    const char *dbg_env = getenv("TSTWO_CFFT_GENERIC");      // debugging aid: 1 = generic kernel for the bottom pass, 2 = for strided passes
-    const int dbg_generic = dbg_env ? atoi(dbg_env) : 0;      // specialised kernels (cfft_fast.cuh); smaller sizes use the generic one
+    const int dbg_generic = kn.cfft_generic;      // experiments build only: 1 = generic kernel for the bottom pass, 2 = for strided passes, 4 = skip the bottom pass
     // All columns go through a pass in one launch.  (Measured on MI355X, 32 x 2^22: running the passes back to back
     // on Infinity-Cache-sized column groups is slower — 688 us ungrouped vs 724/771/879 us for groups of 16/8/4 —
     // the extra launch tails cost more than MALL residency of the intermediate returns.  TSTWO_CFFT_GROUP=k re-enables it.)
     size_t group = n_cols;
-    {
-        const char *ge = getenv("TSTWO_CFFT_GROUP");
-        if (np > 1 && ge && atoi(ge) > 0 && (size_t)atoi(ge) < n_cols) group = (size_t)atoi(ge);
-    }
+    if (np > 1 && kn.cfft_group > 0 && (size_t)kn.cfft_group < n_cols) group = (size_t)kn.cfft_group;
     for (size_t g0 = 0; g0 < n_cols; g0 += group) {
         const size_t gc = n_cols - g0 < group ? n_cols - g0 : group;
         u32 *const *gcols = cols + g0;
@@ -694,8 +684,8 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
     if (!src || !dst) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null column table");
     TSTWO_REQUIRE_TABLE(src, n_cols); TSTWO_REQUIRE_TABLE(dst, n_cols);
     if (log_size == 0 || log_size > 31) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
-    const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
-                       !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_OOP");
+    const Knobs &kn = knobs();
+    const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !kn.cfft_generic && !kn.cfft_kb && !kn.cfft_ka && !kn.cfft_no_oop;
     if (tiled) {
         if (!itw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
         if (tw_log > 31 || ((size_t)1 << (log_size - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
@@ -757,8 +747,8 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
     const u32 ext = log_size - log_poly;
     Pass passes[8];
     int np = 0;
-    const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !getenv("TSTWO_CFFT_GENERIC") && !getenv("TSTWO_CFFT_KB") &&
-                       !getenv("TSTWO_CFFT_KA") && !getenv("TSTWO_CFFT_NO_FUSED_EXTEND");
+    const Knobs &kn = knobs();
+    const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !kn.cfft_generic && !kn.cfft_kb && !kn.cfft_ka && !kn.cfft_no_fused_extend;
     if (tiled) np = plan_passes(log_size, passes, log_size == 14 ? kMaxLogTileB : default_bottom_log(log_size));   // (n = 14: 13 + 1 keeps the fused extension)
     if (tiled && np >= 2 && (ext == 1 || ext == 2) && passes[np - 1].k >= 2) {
         if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");

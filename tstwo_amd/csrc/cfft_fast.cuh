@@ -478,18 +478,10 @@ __global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EX
                     }
                     lds_barrier();   // last access to the tile in LDS: the next column may overwrite it while this stage computes
                     groups_layers<G2, NG, C, LOGT, false>(v, twl, high);
-#ifdef TSTWO_EXP_A_STORE      // upper bound of what 16-byte final stores could buy (WRONG results: the words are not transposed)
-                    {
-                        u32 *vv = &v[0][0];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) gstore4(data + goff(4 * t + j * QT), make_uint4(vv[4 * j], vv[4 * j + 1], vv[4 * j + 2], vv[4 * j + 3]));
-                    }
-#else
 #pragma unroll
                     for (int g = 0; g < NG; g++)
 #pragma unroll
                         for (int m = 0; m < (1 << G2); m++) gstore1(data + goff(e_final(tt, g, m)), v[g][m]);
-#endif
                 }
             }
         }

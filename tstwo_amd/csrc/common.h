@@ -39,6 +39,45 @@ constexpr size_t kResultBytes = 256 * 1024;
 constexpr int kUpSlots = 16;
 constexpr size_t kUpSlotBytes = 16 * 1024;
 
+// Experiment and A/B-timing switches.  The SHIPPED library never takes them from its caller's environment:
+// knobs() is a compile-time constant holding the defaults below, so every branch on a non-default value folds away and a
+// prover's environment can change neither results nor kernel plans.  Built with -DTSTWO_EXPERIMENTS (python -m tstwo_amd.build
+// --experiments -> libtstwo_hip_exp.so; tools/build_variant.sh passes it too) the struct is filled ONCE, at the first use, from
+// the TSTWO_* variables named in the comments (context.hip: read_knobs) — never per call.
+struct Knobs {
+    // cfft.hip
+    int cfft_rounds = 1;               // TSTWO_CFFT_ROUNDS: workgroups per launch as a multiple of the resident slots
+    int cfft_maxwg = 0;                // TSTWO_CFFT_MAXWG: cap on the workgroups per launch (0 = none)
+    int cfft_lds_pad = 0;              // TSTWO_CFFT_LDS_PAD: extra dynamic LDS per workgroup (lowers residency)
+    int cfft_kb = 0, cfft_ka = 0;      // TSTWO_CFFT_KB (11-15) / TSTWO_CFFT_KA (1-10): bottom tile / strided layer limit (0 = planner)
+    int cfft_logta = 0;                // TSTWO_CFFT_LOGTA (12-15): strided tile (0 = planner)
+    int cfft_generic = 0;              // TSTWO_CFFT_GENERIC: bit 0 / 1 generic kernel for bottom / strided passes, bit 2 SKIP the bottom pass
+    int cfft_group = 0;                // TSTWO_CFFT_GROUP: Infinity-Cache column grouping
+    bool cfft_trace = false, cfft_sync = false;             // TSTWO_CFFT_TRACE / TSTWO_CFFT_SYNC
+    bool cfft_no_oop = false, cfft_no_fused_extend = false; // TSTWO_CFFT_NO_OOP / TSTWO_CFFT_NO_FUSED_EXTEND
+    // merkle.hip
+    int merkle_cap = 32;               // TSTWO_MERKLE_CAP: workgroups per CU before lanes grid-stride
+    int merkle_up_log = 0;             // TSTWO_MERKLE_UP_LOG: first quad-lane level (0 = default 16; 15 with UP_ONELANE)
+    int merkle_subtree = 2;            // TSTWO_MERKLE_SUBTREE: column-free layers per launch of the in-lane subtree kernel (0, 2-4)
+    bool merkle_generic = false, merkle_up_onelane = false, merkle_up_smallwg = false, merkle_up_narrow_first = false;
+    bool merkle_no_fused_leaf4 = false, merkle_no_batch = false;
+    // fri.hip
+    bool fri_no_tail = false, fri_no_fold_fusion = false;   // TSTWO_FRI_NO_TAIL / TSTWO_FRI_NO_FOLD_FUSION
+    int fold_cap = 64;                 // TSTWO_FOLD_CAP: workgroups per CU of the fold kernels
+    bool fold1 = false;                // TSTWO_FOLD1: circle fold with one output row per lane
+    // field_ops.hip / quotients.hip
+    int qinv_k = 0;                    // TSTWO_QINV_K
+    bool qinv_montgomery = false, quot_no_lazy = false, quot_no_pair = false;
+    // context.hip
+    bool device_flag = false;          // TSTWO_DEVICE_FLAG: zero-inverse flag / result page in device memory
+};
+#ifdef TSTWO_EXPERIMENTS
+const Knobs &knobs();
+#else
+inline constexpr Knobs kShippedKnobs{};
+inline constexpr const Knobs &knobs() { return kShippedKnobs; }
+#endif
+
 Context &ctx();
 int set_error(int code, const char *msg);
 int set_error(int code, const std::string &msg);

@@ -16,6 +16,41 @@ static thread_local std::string g_last_error;
 
 Context &ctx() { return g_ctx; }
 
+#ifdef TSTWO_EXPERIMENTS
+// The experiments build: every switch of common.h's Knobs from its TSTWO_* variable, read ONCE (first use), never per call.
+static Knobs read_knobs() {
+    Knobs k;
+    auto num = [](const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    k.cfft_rounds = num("TSTWO_CFFT_ROUNDS", 1); if (k.cfft_rounds < 1) k.cfft_rounds = 1;
+    k.cfft_maxwg = num("TSTWO_CFFT_MAXWG", 0); if (k.cfft_maxwg < 0) k.cfft_maxwg = 0;
+    k.cfft_lds_pad = num("TSTWO_CFFT_LDS_PAD", 0);
+    k.cfft_kb = num("TSTWO_CFFT_KB", 0); if (k.cfft_kb < 11 || k.cfft_kb > 15) k.cfft_kb = 0;
+    k.cfft_ka = num("TSTWO_CFFT_KA", 0); if (k.cfft_ka < 1 || k.cfft_ka > 10) k.cfft_ka = 0;
+    k.cfft_logta = num("TSTWO_CFFT_LOGTA", 0); if (k.cfft_logta < 12 || k.cfft_logta > 15) k.cfft_logta = 0;
+    k.cfft_generic = num("TSTWO_CFFT_GENERIC", 0);
+    k.cfft_group = num("TSTWO_CFFT_GROUP", 0);
+    k.cfft_trace = on("TSTWO_CFFT_TRACE"); k.cfft_sync = on("TSTWO_CFFT_SYNC");
+    k.cfft_no_oop = on("TSTWO_CFFT_NO_OOP"); k.cfft_no_fused_extend = on("TSTWO_CFFT_NO_FUSED_EXTEND");
+    k.merkle_cap = num("TSTWO_MERKLE_CAP", 32);
+    k.merkle_up_log = num("TSTWO_MERKLE_UP_LOG", 0);
+    k.merkle_subtree = num("TSTWO_MERKLE_SUBTREE", 2); if (k.merkle_subtree > 4) k.merkle_subtree = 4;
+    k.merkle_generic = on("TSTWO_MERKLE_GENERIC"); k.merkle_up_onelane = on("TSTWO_MERKLE_UP_ONELANE");
+    k.merkle_up_smallwg = on("TSTWO_MERKLE_UP_SMALLWG"); k.merkle_up_narrow_first = on("TSTWO_MERKLE_UP_NARROW_FIRST");
+    k.merkle_no_fused_leaf4 = on("TSTWO_MERKLE_NO_FUSED_LEAF4"); k.merkle_no_batch = on("TSTWO_MERKLE_NO_BATCH");
+    k.fri_no_tail = on("TSTWO_FRI_NO_TAIL"); k.fri_no_fold_fusion = on("TSTWO_FRI_NO_FOLD_FUSION");
+    k.fold_cap = num("TSTWO_FOLD_CAP", 64); k.fold1 = on("TSTWO_FOLD1");
+    k.qinv_k = num("TSTWO_QINV_K", 0); k.qinv_montgomery = on("TSTWO_QINV_MONTGOMERY");
+    k.quot_no_lazy = on("TSTWO_QUOT_NO_LAZY"); k.quot_no_pair = on("TSTWO_QUOT_NO_PAIR");
+    k.device_flag = on("TSTWO_DEVICE_FLAG");
+    return k;
+}
+const Knobs &knobs() {
+    static const Knobs k = read_knobs();
+    return k;
+}
+#endif
+
 int set_error(int code, const char *msg) {
     g_last_error = msg ? msg : "";
     return code;
@@ -116,6 +151,10 @@ int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot
         for (size_t i = 0; i < (size_t)kMaxColsPerLaunch; i++) out.p[i] = const_cast<u32 *>(cols[i < n_cols ? i : 0]);
         return TSTWO_OK;
     }
+    // A table in device memory cannot be part of a captured graph, whether or not this call would have to upload it: the launch
+    // would be recorded against a slot that any later > 64-column call rewrites before the graph is replayed (a cache HIT used
+    // to slip through here — only the upload itself was refused).
+    if (int rc = refuse_if_capturing(c.stream)) return rc;
     if (c.coltab_cap < n_cols) {
         size_t cap = 1024;
         while (cap < n_cols) cap *= 2;
@@ -238,7 +277,11 @@ int trim_locked() {
 extern "C" {
 
 const char *tstwo_last_error(void) { return g_last_error.c_str(); }
+#ifdef TSTWO_EXPERIMENTS
+const char *tstwo_version(void) { return "tstwo_hip 0.1 (gfx950) +experiments"; }
+#else
 const char *tstwo_version(void) { return "tstwo_hip 0.1 (gfx950)"; }
+#endif
 
 int tstwo_device_count(int *out) {
     int n = 0;
@@ -296,7 +339,7 @@ int tstwo_init(int device) {
     {   // error flag: page-locked host memory mapped into the device (read-back of a status word = 9.5 us of synchronisation instead
         // of 15-18 us with a copy); device memory if the mapping is not available
         void *h = nullptr, *d = nullptr;
-        if (!getenv("TSTWO_DEVICE_FLAG") && hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+        if (!knobs().device_flag && hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
             memset(h, 0, 64);
             c.flag_host = (u32 *)h;
             c.flag = (u32 *)d;
@@ -310,7 +353,7 @@ int tstwo_init(int device) {
     if (hipHostMalloc(&c.pinned, kPinnedBytes, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; (void)hipGetLastError(); }
     {   // result page for tstwo_download_many (same mechanism as the flag)
         void *h = nullptr, *d = nullptr;
-        if (!getenv("TSTWO_DEVICE_FLAG") && hipHostMalloc(&h, kResultBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+        if (!knobs().device_flag && hipHostMalloc(&h, kResultBytes, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
             c.result_host = h;
             c.result_dev = d;
         } else {

@@ -470,8 +470,8 @@ int tstwo_qm31_batch_inverse_async(const u32 *const in[4], u32 *const out[4], si
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
     bool aligned = true;
     for (int k = 0; k < 4; k++) aligned = aligned && ((((uintptr_t)in[k]) | ((uintptr_t)out[k])) & 15) == 0;
-    static const int kq = [] { const char *e = getenv("TSTWO_QINV_K"); return e ? atoi(e) : 0; }();      // experiments: 4-byte form, K per lane
-    static const bool mont = getenv("TSTWO_QINV_MONTGOMERY") != nullptr;      // A/B timing: Montgomery's trick over QM31 values
+    const int kq = knobs().qinv_k;      // experiments: 4-byte form, K per lane
+    const bool mont = knobs().qinv_montgomery;      // A/B timing: Montgomery's trick over QM31 values
     if (kq == 0 && aligned && n % 8 == 0 && n >= 8 && !mont) {  // 16-byte accesses, 8 elements per lane, one M31 inversion per 8
         size_t T = n / 8;
         hipLaunchKernelGGL(k_qm31_batch_inverse_norm, dim3(ceil_div(T, 256)), dim3(256), 0, ctx().stream, i4, o4, T, ctx().flag);

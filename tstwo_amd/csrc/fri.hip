@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256) k_eval_partials(const qm31 *__restrict__ 
 
 unsigned capped_blocks(size_t work_items, unsigned threads) {
     unsigned blocks = ceil_div(work_items, threads);
-    static const unsigned mult = getenv("TSTWO_FOLD_CAP") ? (unsigned)atoi(getenv("TSTWO_FOLD_CAP")) : 64u;     // workgroups per CU before lanes grid-stride (8: fold_circle log 24 102 us, fold_line log 23 33.5 us; 32-1024: 97 / 32.5 us)
+    const unsigned mult = (unsigned)knobs().fold_cap;     // workgroups per CU before lanes grid-stride (8: fold_circle log 24 102 us, fold_line log 23 33.5 us; 32-1024: 97 / 32.5 us)
     unsigned cap = (unsigned)ctx().n_cus * mult;
     if (blocks > cap) blocks = cap;
     return blocks ? blocks : 1;
@@ -348,7 +348,7 @@ static void launch_fold_line(const CSoa4 &i4, const Soa4 &o4, size_t n_out, cons
     hipLaunchKernelGGL(k_fold_line, dim3(capped_blocks(n_out, 256)), dim3(256), 0, ctx().stream, i4, o4, n_out, inv_x, alpha, alpha_dev);
 }
 static void launch_fold_circle(bool from_tree, const Soa4 &d4, const CSoa4 &s4, size_t n_out, const u32 *twp, qm31 a, qm31 a2, const qm31 *alpha_dev) {
-    static const bool fold1 = getenv("TSTWO_FOLD1") != nullptr;
+    const bool fold1 = knobs().fold1;
     bool two = from_tree && !fold1 && n_out >= 4;
     for (int k = 0; k < 4; k++) two = two && (((uintptr_t)s4.p[k]) & 15) == 0 && (((uintptr_t)d4.p[k]) & 7) == 0;
     if (two)
@@ -563,7 +563,7 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
         const u32 *seg1 = itw + ((size_t)1 << tw_log) - ((size_t)1 << (col_logs[0] - 1));
         Soa4 d4 = {{cur[0], cur[1], cur[2], cur[3]}};
         CSoa4 s4 = {{circle_cols[0], circle_cols[1], circle_cols[2], circle_cols[3]}};
-        bool two = cur_log >= 2 && !getenv("TSTWO_FOLD1");
+        bool two = cur_log >= 2 && !knobs().fold1;
         for (int k = 0; k < 4; k++) two = two && (((uintptr_t)s4.p[k]) & 15) == 0 && (((uintptr_t)d4.p[k]) & 7) == 0;
         if (two)
             hipLaunchKernelGGL(k_fold_circle2<false>, dim3(capped_blocks((size_t)1 << (cur_log - 1), 256)), dim3(256), 0, ctx().stream, d4, s4,
@@ -581,7 +581,7 @@ int tstwo_fri_commit_layers(const u32 *const *circle_cols, const u32 *col_logs, 
         return r;
     };
     size_t n = 0;
-    static const bool no_tail = getenv("TSTWO_FRI_NO_TAIL") != nullptr;      // A/B timing: per-layer launches down to the last layer
+    const bool no_tail = knobs().fri_no_tail;      // A/B timing: per-layer launches down to the last layer
     uint8_t *cur_tree = nullptr;         // set: `cur` is already committed into it (its leaves were hashed by the fold that produced it)
                                          // and alpha (n + 1) is drawn
     uint8_t *spare_tree = nullptr;       // a tree buffer of the current size allocated for a fusion that an override refused

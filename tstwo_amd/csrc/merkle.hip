@@ -222,27 +222,12 @@ __global__ void __launch_bounds__(256) k_merkle_leaf_static(HashColPtrs cols, Tr
             const int bn = (b + 1) % NBLK;
             const u32 src = (u32)((b + 1 < NBLK) ? nc : nn) * 4u;
 #pragma unroll
-#ifdef TSTWO_EXP_LEAF_NOLOAD      // experiment: the kernel's ALU side alone (WRONG results)
-            for (int k = 0; k < 16; k++) nxt[k] = cur[(k + 1) & 15] + src;
-#else
             for (int k = 0; k < 16; k++) nxt[k] = word(16 * bn + k, src);
-#endif
             if (b == 0 && pnode < n_nodes) {
-#ifdef TSTWO_EXP_LEAF_COALESCED_STORE      // experiment: upper bound of coalesced digest stores (WRONG layout)
-                const size_t wb = 2 * (pnode - (threadIdx.x & 63));
-                out[wb + (threadIdx.x & 63)] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-                out[wb + 64 + (threadIdx.x & 63)] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
-#else
                 out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
                 out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
-#endif
             }
-#ifdef TSTWO_EXP_LEAF_NOHASH      // experiment: the kernel's memory side alone (WRONG results)
-#pragma unroll
-            for (int k = 0; k < 16; k++) h[k & 7] ^= cur[k];
-#else
             b2s_compress(h, cur, 64u * (b + 1), b == NBLK - 1);
-#endif
 #pragma unroll
             for (int k = 0; k < 16; k++) cur[k] = nxt[k];
         }
@@ -301,17 +286,9 @@ __global__ void __launch_bounds__(256) k_merkle_leaf4(u32 *__restrict__ c0, u32 
         if (FOLD) {
             nfr = fold_row_load(fs, nn);                             // next node's rows in flight during the compression
         } else {
-#ifdef TSTWO_EXP_L4_NOLOAD       // experiment: ALU + stores only (WRONG results)
-            na = a + on; nb = b ^ on; ncc = c + 1u; nd = d + on;
-#else
             na = word(c0, on); nb = word(c1, on); ncc = word(c2, on); nd = word(c3, on);      // next node's words in flight during the compression
-#endif
         }
-#ifdef TSTWO_EXP_L4_NOSTORE      // experiment: (practically) no stores (WRONG results)
-        if (pnode < n_nodes && hp[0] == 0x12345678u && hp[1] == 0x9abcdef0u) {
-#else
         if (pnode < n_nodes) {
-#endif
             out[2 * pnode] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
             out[2 * pnode + 1] = make_uint4(hp[4], hp[5], hp[6], hp[7]);
         }
@@ -723,11 +700,13 @@ __global__ void __launch_bounds__(WG) k_merkle_leaf4_upq(u32 *__restrict__ c0, u
 // Set by the FRI commit loop around a tstwo_merkle_commit call: the single-workgroup launch that produces the root takes the
 // channel step with it and clears the hook; a hook still set afterwards means the tree went another way (the caller then
 // launches k_channel_mix_draw itself).
-ChanHook g_chan_hook = {nullptr, nullptr};
+// (thread_local: the hooks belong to the call chain that set them — a second host thread committing a tree of its own while
+// tstwo_fri_commit_layers is between "set" and "consumed" must not pick them up.)
+thread_local ChanHook g_chan_hook = {nullptr, nullptr};
 // Likewise for a fold: set by merkle_commit4_folded around a tstwo_merkle_commit of the 4 NEW coordinate columns; the leaf launch
 // of that tree folds the previous layer into them on the way (FoldSpec) and clears it.
-FoldSpec g_fold = {};
-bool g_fold_set = false;
+thread_local FoldSpec g_fold = {};
+thread_local bool g_fold_set = false;
 int commit_upper_levels(uint8_t *layers, u32 log_child, u32 log_stop);
 int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_stop) {
     Context &c = ctx();
@@ -739,9 +718,9 @@ int commit_upper_levels(TreeSet ts, unsigned n_trees, u32 log_child, u32 log_sto
         return h;
     };
     uint8_t *layers = (uint8_t *)ts.t[0];             // (the one-lane scheme kept for A/B timing handles one tree)
-    static const bool one_lane = getenv("TSTWO_MERKLE_UP_ONELANE") != nullptr;     // previous scheme, kept for A/B timing
-    static const bool small_wg = getenv("TSTWO_MERKLE_UP_SMALLWG") != nullptr;     // 256-lane workgroups only (A/B timing)
-    static const bool narrow_first = getenv("TSTWO_MERKLE_UP_NARROW_FIRST") != nullptr;   // 64-quad workgroups first, one 256-quad workgroup last (A/B timing)
+    const bool one_lane = knobs().merkle_up_onelane;     // previous scheme, kept for A/B timing
+    const bool small_wg = knobs().merkle_up_smallwg;     // 256-lane workgroups only (A/B timing)
+    const bool narrow_first = knobs().merkle_up_narrow_first;   // 64-quad workgroups first, one 256-quad workgroup last (A/B timing)
     while (log_child > log_stop) {
         const u32 remaining = log_child - log_stop;
         const u32 parents_log = log_child - 1;
@@ -943,10 +922,10 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
     const u32 child_words = prev ? 16u : 0u;
     const u32 W = child_words + (u32)n_cols;
     unsigned blocks = ceil_div(n_nodes, 256);
-    static const unsigned cap_mult = getenv("TSTWO_MERKLE_CAP") ? (unsigned)atoi(getenv("TSTWO_MERKLE_CAP")) : 32u;
+    const unsigned cap_mult = (unsigned)knobs().merkle_cap;
     const unsigned cap = (unsigned)c.n_cus * cap_mult;     // workgroups per CU before lanes grid-stride over more nodes
     if (blocks > cap) blocks = cap;
-    if (!prev && log_size <= 30 && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !getenv("TSTWO_MERKLE_GENERIC")) {
+    if (!prev && log_size <= 30 && (n_cols == 16 || n_cols == 32 || n_cols == 48 || n_cols == 64) && !knobs().merkle_generic) {
         HashColPtrs hp;
         for (size_t k = 0; k < n_cols; k++) hp.p[k] = cols[k];
         TreeSet one = {};
@@ -960,7 +939,7 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
     }
-    if (!prev && log_size <= 30 && n_cols == 4 && !getenv("TSTWO_MERKLE_GENERIC")) {
+    if (!prev && log_size <= 30 && n_cols == 4 && !knobs().merkle_generic) {
         u32 *w0 = const_cast<u32 *>(cols[0]), *w1 = const_cast<u32 *>(cols[1]), *w2 = const_cast<u32 *>(cols[2]), *w3 = const_cast<u32 *>(cols[3]);
         if (g_fold_set) {
             hipLaunchKernelGGL(k_merkle_leaf4<true>, dim3(blocks), dim3(256), 0, c.stream, w0, w1, w2, w3, (uint4 *)out, n_nodes, g_fold);
@@ -971,7 +950,7 @@ int commit_layer(u32 log_size, const uint8_t *prev, const u32 *const *cols, size
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
     }
-    if (prev && n_cols == 0 && !getenv("TSTWO_MERKLE_GENERIC")) {
+    if (prev && n_cols == 0 && !knobs().merkle_generic) {
         hipLaunchKernelGGL(k_merkle_inner, dim3(blocks), dim3(256), 0, c.stream, (const uint4 *)prev, (uint4 *)out, n_nodes);
         TSTWO_LAUNCH_CHECK();
         return TSTWO_OK;
@@ -1031,7 +1010,7 @@ int merkle_commit_then_channel(const u32 *const *cols, const u32 *log_sizes, siz
 // override routes 4-column trees away from the leaf4 kernels).
 int merkle_commit4_folded(const u32 *const prev[4], u32 log_new, const u32 *inv_x, const u32 *alpha_dev, u32 *const new_cols[4],
                           uint8_t *layers, u32 *chan, u32 *felt) {
-    const bool fusable = !getenv("TSTWO_MERKLE_GENERIC") && !getenv("TSTWO_MERKLE_NO_FUSED_LEAF4") && !getenv("TSTWO_FRI_NO_FOLD_FUSION") && log_new >= 1 &&
+    const bool fusable = !knobs().merkle_generic && !knobs().merkle_no_fused_leaf4 && !knobs().fri_no_fold_fusion && log_new >= 1 &&
                          log_new <= 30;
     const u32 lg4[4] = {log_new, log_new, log_new, log_new};
     if (!fusable) return -1;                                     // caller takes the unfused path
@@ -1390,12 +1369,11 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
         if (log_sizes[i] > max_log) max_log = log_sizes[i];
     }
     // layers below 2^up_log nodes are latency-bound: fused multi-level launches (k_merkle_upq) instead of one per level
-    static const int up_log = getenv("TSTWO_MERKLE_UP_LOG") ? atoi(getenv("TSTWO_MERKLE_UP_LOG"))
-                              : (getenv("TSTWO_MERKLE_UP_ONELANE") ? 15 : 16);
+    const int up_log = knobs().merkle_up_log ? knobs().merkle_up_log : (knobs().merkle_up_onelane ? 15 : 16);
     // a tree of exactly 4 equally long columns with at most 2^up_log rows (every FRI layer but the first few): leaves and the
     // first 7 (or all, below 2^10 rows) levels in one launch
     if (n_cols == 4 && max_log >= 1 && (int)max_log <= up_log && log_sizes[0] == max_log && log_sizes[1] == max_log && log_sizes[2] == max_log &&
-        log_sizes[3] == max_log && !getenv("TSTWO_MERKLE_NO_FUSED_LEAF4")) {
+        log_sizes[3] == max_log && !knobs().merkle_no_fused_leaf4) {
         Context &c = ctx();
         u32 log_child = max_log;
         u32 *w0 = const_cast<u32 *>(cols[0]), *w1 = const_cast<u32 *>(cols[1]), *w2 = const_cast<u32 *>(cols[2]), *w3 = const_cast<u32 *>(cols[3]);
@@ -1418,7 +1396,7 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
         if (root) return small_d2h(root, layers, 32);
         return TSTWO_OK;
     }
-    static const int sub_levels = [] { const char *e = getenv("TSTWO_MERKLE_SUBTREE"); int v = e ? atoi(e) : 2; return v > 4 ? 4 : v; }();   // measured: 2 (0.308 ms) < off (0.313) < 3 (0.326) < 4 (0.332) for 32 x 2^22
+    const int sub_levels = knobs().merkle_subtree;   // measured: 2 (0.308 ms) < off (0.313) < 3 (0.326) < 4 (0.332) for 32 x 2^22
     const u32 **lc = n_cols ? new const u32 *[n_cols] : nullptr;
     const uint8_t *prev = nullptr;
     int rc = TSTWO_OK;
@@ -1492,8 +1470,8 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
 int tstwo_merkle_commit_many(const tstwo_commit_request *reqs, size_t n_trees, uint8_t *roots) {
     TSTWO_REQUIRE_READY();
     if (n_trees && !reqs) return set_error(TSTWO_ERR_BAD_ARG, "merkle: null request table");
-    bool uniform = n_trees >= 2 && n_trees <= (size_t)kMaxTrees && !getenv("TSTWO_MERKLE_GENERIC") && !getenv("TSTWO_MERKLE_NO_BATCH");
-    static const int up_log = getenv("TSTWO_MERKLE_UP_LOG") ? atoi(getenv("TSTWO_MERKLE_UP_LOG")) : 16;
+    bool uniform = n_trees >= 2 && n_trees <= (size_t)kMaxTrees && !knobs().merkle_generic && !knobs().merkle_no_batch;
+    const int up_log = knobs().merkle_up_log ? knobs().merkle_up_log : 16;
     size_t n_cols = n_trees ? reqs[0].n_cols : 0;
     u32 lg = 0;
     for (size_t r = 0; r < n_trees && uniform; r++) {
@@ -1524,7 +1502,7 @@ int tstwo_merkle_commit_many(const tstwo_commit_request *reqs, size_t n_trees, u
         }
         const size_t n_nodes = (size_t)1 << lg;
         unsigned blocks = ceil_div(n_nodes, 256);
-        static const unsigned cap_mult = getenv("TSTWO_MERKLE_CAP") ? (unsigned)atoi(getenv("TSTWO_MERKLE_CAP")) : 32u;
+        const unsigned cap_mult = (unsigned)knobs().merkle_cap;
         const unsigned cap = (unsigned)c.n_cus * cap_mult / (unsigned)n_trees;          // the same lanes in flight as one tree's launch
         if (blocks > cap) blocks = cap ? cap : 1;
         const dim3 grid(blocks, (unsigned)n_trees);

@@ -509,11 +509,11 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         cpoint qb = {qx, qy};
         size_t n_threads = (size_t)1 << (log_size - 3);
         bool lazy = false;               // a batch with more than 4 column entries: fold the numerator sums between groups
-        static const bool no_lazy = getenv("TSTWO_QUOT_NO_LAZY") != nullptr;          // (measurement knob: reduce after every group of 4)
+        const bool no_lazy = knobs().quot_no_lazy;          // (measurement knob: reduce after every group of 4)
         for (size_t b = 0; b < n_batches; b++) lazy = lazy || (!no_lazy && batch_off[b + 1] - batch_off[b] > 4);
         const dim3 grid(ceil_div(n_threads, 256));
         // two batches over one column list (same columns in the same order): the column words are loaded once for both
-        static const bool no_pair = getenv("TSTWO_QUOT_NO_PAIR") != nullptr;          // (A/B timing)
+        const bool no_pair = knobs().quot_no_pair;          // (A/B timing)
         bool pair = n_batches == 2 && !no_pair && batch_off[1] - batch_off[0] == batch_off[2] - batch_off[1] && batch_off[1] > batch_off[0];
         for (size_t j = batch_off[0]; pair && j < batch_off[1]; j++) pair = col_idx[j] == col_idx[j - batch_off[0] + batch_off[1]];
         if (pair) {

@@ -393,28 +393,38 @@ class FriProver:
         logs = [c.domain.logSize() for c in columns]
         first_log = logs[0] - CIRCLE_TO_LINE_FOLD_STEP
         last_log = config.last_layer_domain_size().bit_length() - 1
-        cap = max(first_log - last_log, 0) + 1
+        if first_log < last_log:
+            raise ValueError("last layer domain size mismatch")          # what commitLastLayer (fri.ts:718-754) says for this config
+        cap = first_log - last_log + 1
         outs = (L.FriLayerOut * cap)()
         n_out, first = C.c_size_t(0), L.vp()
         L.call("tstwo_fri_commit_layers", L.ptr_array([cc.ptr for c in columns for cc in c.values.columns]), L.u32x(logs), len(columns),
                C.c_void_p(twiddles.itwiddles.ptr), twiddles.log_size, last_log, C.c_void_p(dch.buf.ptr), C.c_void_p(alphas.ptr),
                alphas.nbytes // 16, C.byref(first), outs, cap, C.byref(n_out))
+        # every block the library handed out is adopted HERE, before any other object is built: an exception further down must not
+        # leak the blocks not yet wrapped
+        first_buf = L.DeviceBuffer.adopt(first.value, 32 * ((2 << logs[0]) - 1))
+        adopted = []
+        for i in range(n_out.value):
+            o = outs[i]
+            n = 1 << o.log_size
+            cols = [L.DeviceBuffer.adopt(o.cols[k], 4 * n) for k in range(4)]
+            tree = L.DeviceBuffer.adopt(o.layers, 32 * ((2 << o.log_size) - 1)) if o.layers else None
+            adopted.append((o.log_size, cols, tree))
 
-        def tree_of(ptr, max_log):
-            buf = L.DeviceBuffer.adopt(ptr, 32 * ((2 << max_log) - 1))
+        def tree_of(buf, max_log):
             return MerkleProver(TreeLayers(buf, max_log), buf, None)
 
-        def eval_of(o, domain):
-            n = 1 << o.log_size
-            cols = [HipColumn(_buf=L.DeviceBuffer.adopt(o.cols[k], 4 * n), _len=n) for k in range(4)]
-            return LineEvaluation(domain, SecureColumnByCoords(cols))
-        first_layer = FriFirstLayerProver(columns, tree_of(first.value, logs[0]))
+        def eval_of(entry, domain):
+            n = 1 << entry[0]
+            return LineEvaluation(domain, SecureColumnByCoords([HipColumn(_buf=b, _len=n) for b in entry[1]]))
+        first_layer = FriFirstLayerProver(columns, tree_of(first_buf, logs[0]))
         domain = LineDomain(Coset.half_odds(first_log))
         inner = []
-        for i in range(n_out.value - 1):
-            inner.append(FriInnerLayerProver(eval_of(outs[i], domain), tree_of(outs[i].layers, outs[i].log_size)))
+        for entry in adopted[:-1]:
+            inner.append(FriInnerLayerProver(eval_of(entry, domain), tree_of(entry[2], entry[0])))
             domain = domain.double()
-        return first_layer, inner, eval_of(outs[n_out.value - 1], domain)
+        return first_layer, inner, eval_of(adopted[-1], domain)
 
     @staticmethod
     def _commit_layers(config: FriConfig, columns, twiddles: TwiddleTree, transcript) -> tuple:
