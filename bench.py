@@ -488,7 +488,10 @@ def main():
         cfft_ms = t_cfft / steps
         merkle_ms = t_merkle / steps
         # dominant kernel: the CFFT pass kernels (fast::k_cfft_a<INV,K>, fast::k_cfft_b<INV,LOGT>), (passes) launches per step over all columns.
-        passes = 1 if n <= 13 else 1 + -(-(n - 13) // 9)
+        # (launch count from the planner itself: tstwo_cfft_plan_passes — 2 at n = 22 .. 24, 1 up to n = 14)
+        n_passes = C.c_uint32(0)
+        L.call("tstwo_cfft_plan_passes", n, n_cols, C.byref(n_passes))
+        passes = int(n_passes.value)
         algo_bytes_transform = 8.0 * N * n_cols                     # 8*N per column transform
         algo_bytes_launch = algo_bytes_transform / passes
         launch_ms = cfft_ms / passes
@@ -534,7 +537,7 @@ def main():
             "merkle_ms": merkle_ms,
             "merkle_GBps": merkle_bytes / (merkle_ms * 1e-3) / 1e9,
             "merkle_frac_of_hbm_peak": merkle_bytes / (merkle_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9,0,14> + fast::k_cfft_b<false,13,false> (the two passes of one transform)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "fast::k_cfft_a<false,9,0,15> + fast::k_cfft_b<false,13,false> (the two passes of one transform)" if n == 22 else f"the {passes} CFFT pass kernel(s) of one transform", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "launches_per_step": passes, "avg_launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_launch, "lib_sha16": lib_now,

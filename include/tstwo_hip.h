@@ -161,6 +161,10 @@ int tstwo_cfft_interpolate_to(const uint32_t *const *src, uint32_t *const *dst, 
  * log_size < log_poly -> TSTWO_ERR_LOG_SIZE ("log size too small"). */
 int tstwo_cfft_evaluate_extended(const uint32_t *const *polys, uint32_t log_poly, uint32_t *const *out, size_t n_cols,
                                  uint32_t log_size, uint32_t half_initial, const uint32_t *tw, uint32_t tw_log);
+/* How many passes over HBM (= kernel launches, each reading and writing every column once) tstwo_cfft_evaluate /
+ * tstwo_cfft_interpolate take for n_cols columns of 2^log_size words — the planner's own answer, for callers that price a
+ * transform against the memory roofline (bench.py: roofline.launches_per_step).  Host-side only, touches no device state. */
+int tstwo_cfft_plan_passes(uint32_t log_size, size_t n_cols, uint32_t *n_passes);
 /* PolyOps.extend (circle.ts:71-82): dst[0..2^log_dst) = src[0..2^log_src) zero-padded.
  * log_dst < log_src -> TSTWO_ERR_LOG_SIZE ("log size too small"). */
 int tstwo_poly_extend(const uint32_t *src, uint32_t log_src, uint32_t *dst, uint32_t log_dst);

@@ -65,6 +65,9 @@ def _is_light(ins):
 @pytest.mark.parametrize("tu,pattern,min_phases,min_light_share", [
     ("cfft", r"k_cfft_bILb0ELi13ELb0E", 40, 0.9), ("cfft", r"k_cfft_bILb1ELi13ELb0E", 40, 0.9),
     ("cfft", r"k_cfft_aILb0ELi9ELi0ELi14E", 30, 0.9), ("cfft", r"k_cfft_aILb1ELi9ELi0ELi14E", 30, 0.9),
+    # round 4: the 10-layer strided pass on the 2^15-word tile (n = 24 in two passes), both directions and the fused extension
+    ("cfft", r"k_cfft_aILb0ELi9ELi0ELi15E", 60, 0.9), ("cfft", r"k_cfft_aILb1ELi9ELi0ELi15E", 60, 0.9),       # the headline strided pass since round 4 (n = 22: 13 + 9)
+    ("cfft", r"k_cfft_aILb0ELi10ELi0ELi15E", 60, 0.9), ("cfft", r"k_cfft_aILb1ELi10ELi0ELi15E", 60, 0.9), ("cfft", r"k_cfft_aILb0ELi10ELi2ELi15E", 50, 0.9),
     ("merkle", r"k_merkle_leaf_staticILi2E", 300, 0.9), ("merkle", r"k_merkle_innerE", 150, 0.9),
     # round 3: the 8-rows-per-lane field kernels on field8.cuh (quotients, QM31 batch inverse through the norms).  Their
     # priority-0 stretches also hold what cannot be phased — the one Fermat chain per 8 values and the tree products around it

@@ -409,7 +409,7 @@ print(bytes(root).hex(), hashlib.blake2s(b"".join(l.tobytes() for l in layers)).
 """
 
 
-@pytest.mark.parametrize("levels", ["0", "3", "4"])
+@pytest.mark.parametrize("levels", ["0", "3", "4", "2-lane-stride"])
 def test_merkle_subtree_levels_agree(levels):
     """TSTWO_MERKLE_SUBTREE (experiments build only; read once per process): every setting (layer per launch, 3 and 4 layers per
     in-lane subtree; 2 is the default the other tests run) must give the oracle's tree."""
@@ -423,6 +423,8 @@ def test_merkle_subtree_levels_agree(levels):
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     script = _SUBTREE_SCRIPT.format(root=os.path.dirname(tests_dir), tests=tests_dir)
     env = dict(os.environ, TSTWO_MERKLE_SUBTREE=levels, TSTWO_HIP_LIB=L.LIB_EXP_PATH)
+    if levels == "2-lane-stride":         # round 3's two-level kernel (lane-strided accesses) instead of the coalesced k_merkle_subtree2c
+        env.update(TSTWO_MERKLE_SUBTREE="2", TSTWO_MERKLE_SUBTREE_LANE_STRIDE="1")
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1] == want
@@ -570,7 +572,7 @@ def test_cfft_evaluate_extended_errors():
         L.call("tstwo_cfft_evaluate_extended", L.ptr_array([a.ptr]), 13, L.ptr_array([c.ptr]), 1, 15, 1 << 15, vp(tw), 12)
 
 
-@pytest.mark.parametrize("n", [3, 8, 12, 13, 14, 16, 19, 22, 23])
+@pytest.mark.parametrize("n", [3, 8, 12, 13, 14, 16, 19, 22, 23, 24])
 def test_cfft_interpolate_to_matches_in_place(n):
     """tstwo_cfft_interpolate_to (source untouched, copy folded into the first pass) == copy + tstwo_cfft_interpolate."""
     n_cols = 3 if n <= 20 else 2
@@ -591,14 +593,15 @@ def test_cfft_interpolate_to_matches_in_place(n):
     assert (dst[0].download() == evals[0]).all()
 
 
-def test_cfft_log23_two_pass_plan_vs_oracle():
-    """n = 23 is the one size whose default plan uses the 2^14-word bottom tile (14 + 9 layers, two passes): evaluate, interpolate,
-    the out-of-place interpolate and the fused extension (21 -> 23, 22 -> 23) against the oracle, every word."""
-    n = 23
+@pytest.mark.parametrize("n", [23, 24])
+def test_cfft_two_pass_plans_above_log22_vs_oracle(n):
+    """n = 23 (14 + 9 layers on the 2^14-word bottom tile) and n = 24 (14 + 10: the strided pass on the 2^15-word tile, two virtual
+    lanes per lane, scalar-base addressing) are TWO passes over memory: evaluate, interpolate, the out-of-place interpolate and the
+    fused extension (n - 2 -> n, n - 1 -> n) against the oracle, every word."""
     half = half_odds(n - 1)
     tw, itw = build_twiddles(n - 1)
     otw, oitw = orc.precompute_twiddles(half, n - 1)
-    cols = [rand_column(23000 + c, 1 << n) for c in range(2)]
+    cols = [rand_column(1000 * n + c, 1 << n) for c in range(2)]
     want = [orc.cfft_evaluate(c, n, half, otw, n - 1) for c in cols]
     d = [dev(c) for c in cols]
     L.call("tstwo_cfft_evaluate", ptrs(d), 2, n, half, vp(tw), n - 1)
@@ -610,18 +613,18 @@ def test_cfft_log23_two_pass_plan_vs_oracle():
     for c in range(2):
         assert (dst[c].download() == cols[c]).all() and (host(d[c], 1 << n) == want[c]).all()
     # in-place interpolation of arbitrary values against the oracle
-    vals = rand_column(23100, 1 << n)
+    vals = rand_column(1000 * n + 100, 1 << n)
     dv = [dev(vals)]
     L.call("tstwo_cfft_interpolate", ptrs(dv), 1, n, half, vp(itw), n - 1)
     assert (host(dv[0], 1 << n) == orc.cfft_interpolate(vals, n, half, oitw, n - 1)).all()
-    # fused extension: polynomials of log 21 / 22 evaluated on the log-23 domain == zero-padded coefficients transformed
-    for log_poly in (21, 22):
-        poly = rand_column(23200 + log_poly, 1 << log_poly)
+    # fused extension: polynomials of log n - 2 / n - 1 evaluated on the log-n domain == zero-padded coefficients transformed
+    for log_poly in (n - 2, n - 1):
+        poly = rand_column(1000 * n + 200 + log_poly, 1 << log_poly)
         padded = np.zeros(1 << n, dtype=np.uint32)
         padded[:1 << log_poly] = poly
         out, src = [L.DeviceBuffer(4 << n)], [dev(poly)]
         L.call("tstwo_cfft_evaluate_extended", ptrs(src), log_poly, ptrs(out), 1, n, half, vp(tw), n - 1)
-        assert (out[0].download() == orc.cfft_evaluate(padded, n, half, otw, n - 1)).all(), f"extended {log_poly} -> 23"
+        assert (out[0].download() == orc.cfft_evaluate(padded, n, half, otw, n - 1)).all(), f"extended {log_poly} -> {n}"
 
 
 @pytest.mark.parametrize("n", [25, 26, 27, 28, 29, 30])
@@ -871,8 +874,8 @@ def test_device_pointer_table_is_refused_during_capture_on_a_cache_hit_too():
     capture: error; and the eager call still works afterwards."""
     evs_host = [rand_column(1990 + i, 1 << 13) for i in range(70)]
     evs = [dev(e) for e in evs_host]
-    tw = dev_empty(1 << 12)
-    L.call("tstwo_twiddles_build", half_odds(12), 12, vp(tw), vp(None))
+    tw, itw = dev_empty(1 << 12), dev_empty(1 << 12)
+    L.call("tstwo_twiddles_build", half_odds(12), 12, vp(tw), vp(itw))
     table = ptrs(evs)
     L.call("tstwo_cfft_evaluate", table, len(evs), 13, half_odds(12), vp(tw), 12)        # fills the slot: the next call is a hit
     L.sync()
@@ -888,8 +891,6 @@ def test_device_pointer_table_is_refused_during_capture_on_a_cache_hit_too():
             pass
         if h.value:
             L.call("tstwo_graph_destroy", h)
-    itw = dev_empty(1 << 12)
-    L.call("tstwo_twiddles_build", half_odds(12), 12, vp(None), vp(itw))
     L.call("tstwo_cfft_interpolate", table, len(evs), 13, half_odds(12), vp(itw), 12)
     for i in (0, 33, 69):
         assert (host(evs[i], 1 << 13) == evs_host[i]).all()

@@ -60,6 +60,7 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_cfft_interpolate: { args: [P, u64, u32, u32, u64, u32], returns: i32 },
   tstwo_cfft_interpolate_to: { args: [P, P, u64, u32, u32, u64, u32], returns: i32 },
   tstwo_cfft_evaluate_extended: { args: [P, u32, P, u64, u32, u32, u64, u32], returns: i32 },
+  tstwo_cfft_plan_passes: { args: [u32, u64, P], returns: i32 },
   tstwo_poly_extend: { args: [u64, u32, u64, u32], returns: i32 },
   tstwo_eval_at_point: { args: [u64, u32, P, P, P], returns: i32 },
   tstwo_eval_at_point_batch: { args: [P, u64, u32, P, P, P], returns: i32 },

@@ -105,6 +105,7 @@ _SIGS = {
     "tstwo_cfft_interpolate": [C.POINTER(vp), C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_uint32],
     "tstwo_cfft_interpolate_to": [C.POINTER(vp), C.POINTER(vp), C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_uint32],
     "tstwo_cfft_evaluate_extended": [C.POINTER(vp), C.c_uint32, C.POINTER(vp), C.c_size_t, C.c_uint32, C.c_uint32, vp, C.c_uint32],
+    "tstwo_cfft_plan_passes": [C.c_uint32, C.c_size_t, u32p],
     "tstwo_poly_extend": [vp, C.c_uint32, vp, C.c_uint32],
     "tstwo_eval_at_point": [vp, C.c_uint32, u32p, u32p, u32p],
     "tstwo_eval_at_point_batch": [C.POINTER(vp), C.c_size_t, C.c_uint32, u32p, u32p, u32p],

@@ -370,13 +370,30 @@ int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA, u3
     return cnt;
 }
 
-// Bottom tile of the default plan.  2^13 words everywhere but at n = 23, where a 2^14-word tile (1024 lanes, 72 KiB of LDS) makes
-// the transform 14 + 9 layers = TWO passes over memory instead of 13 + 5 + 5 = three: 16 x 2^23 in 499 against 650 us forward,
-// 532 against 667 us inverse.  At n = 22 the larger tile loses (14 + 8: 240 against 228 us), at n >= 24 nothing changes the pass
-// count (a 10-layer strided pass with 64-byte rows costs what it saves).
-// n = 14 likewise is ONE pass on the 2^14 tile instead of 13 + 1 (256 columns 16.4 against 21.2 us, 2048 columns 84 against 115 us;
-// a handful of columns: the same 12 us either way).
-inline u32 default_bottom_log(u32 n) { return (n == 23 || n == 14) ? 14u : kMaxLogTileB; }
+// The default plan of a many-column transform (evaluate / interpolate / interpolate_to / evaluate_extended share it):
+//   n <= 13, n = 14      ONE pass on the contiguous tile (2^14 words at n = 14: 256 columns 16.4 against 21.2 us for 13 + 1);
+//   15 <= n <= 21        13 bottom layers + one strided pass on 2^14-word tiles;
+//   n = 22, 23           13 + 9 / 13 + 10 with the strided pass on the 2^15-word tile (k_cfft_a<., K, ., 15>: two virtual lanes per
+//                        lane, 256- / 128-byte rows) when the launch still has two workgroups per CU — round 4, same box, 256 x 2^22:
+//                        3.775 against 3.805 ms forward, 3.985 against 4.027 inverse; 128 x 2^23: 3.815 against 3.895 (14 + 9 on
+//                        2^14-word tiles, round 3's two-pass plan, which stays for few columns) and 4.02 against 4.08;
+//   n = 24               14 + 10, the strided pass on the 2^15-word tile: TWO passes instead of 13 + 6 + 5 (round 4: 32 x 2^24
+//                        2.09 against 2.66 ms, 64 columns 4.08 against 5.29);
+//   n >= 25              13 bottom layers + two strided passes (a 2^14-word bottom tile changes nothing there).
+// 12 + 10 at n = 22 (a layer moved from the issue-bound bottom pass to the HBM-bound strided one) measured 3.86 against 3.78.
+struct PlanShape { u32 kb, ka_max, logta; };
+inline PlanShape default_shape(u32 n, size_t n_cols) {
+    const bool wide = n >= 15 && (((size_t)1 << (n - 15)) * n_cols) >= (size_t)2 * (size_t)ctx().n_cus;     // the 2^15 tile halves the workgroup count
+    if (n == 24) return {14u, 10u, 15u};
+    if (n == 23) return wide ? PlanShape{13u, 10u, 15u} : PlanShape{14u, kMaxKA, kLogTileA};
+    if (n == 22 && wide) return {13u, 9u, 15u};
+    if (n == 14) return {14u, kMaxKA, kLogTileA};
+    return {kMaxLogTileB, kMaxKA, kLogTileA};
+}
+inline int plan_default(u32 n, size_t n_cols, Pass *out) {
+    const PlanShape sh = default_shape(n, n_cols);
+    return plan_passes(n, out, sh.kb, sh.ka_max, sh.logta);
+}
 
 template <bool INV, int THREADS>
 int launch_pass_t(u32 *const *cols, size_t n_cols, const PassParams &pp0) {
@@ -482,17 +499,17 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
 template <bool INV, int K, int LOGTA = 14>
 int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, u32 scale) {
     const size_t tiles = (size_t)1 << (n - LOGTA);
-    return launch_fast_kernel(fast::k_cfft_a<INV, K, 0, LOGTA>, 1 << (LOGTA - 4),
+    return launch_fast_kernel(fast::k_cfft_a<INV, K, 0, LOGTA>, LOGTA == 15 ? 1024 : 1 << (LOGTA - 4),
                               ((size_t)(1 << LOGTA) + (1 << (LOGTA - 5)) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols, n, lo, tw_end, scale);
 }
 
 // First forward pass of an evaluation whose input is a smaller polynomial (log size n - EXT) in its own buffers.
-template <int K, int EXT>
+template <int K, int EXT, int LOGTA = 14>
 int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, u32 lo, const u32 *tw_end) {
     Context &c = ctx();
-    const size_t tiles = (size_t)1 << (n - 14);
-    const size_t lds_bytes = ((size_t)(1 << 14) + (1 << 9) + ((size_t)1 << K)) * sizeof(u32);
-    auto kernel = fast::k_cfft_a<false, K, EXT>;
+    const size_t tiles = (size_t)1 << (n - LOGTA);
+    const size_t lds_bytes = ((size_t)(1 << LOGTA) + (1 << (LOGTA - 5)) + ((size_t)1 << K)) * sizeof(u32);
+    auto kernel = fast::k_cfft_a<false, K, EXT, LOGTA>;
     { int rc_attr = allow_big_lds((const void *)kernel); if (rc_attr) return rc_attr; }
     {
         const size_t cnt = n_cols;
@@ -509,7 +526,12 @@ int launch_a_ext(u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, 
     return TSTWO_OK;
 }
 template <int EXT>
-int launch_a_ext_k(u32 k, u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, u32 lo, const u32 *tw_end) {
+int launch_a_ext_k(u32 k, u32 logta, u32 *const *cols, const u32 *const *src, size_t n_cols, u32 n, u32 lo, const u32 *tw_end) {
+    if (logta == 15) {
+        if (k == 10) return launch_a_ext<10, EXT, 15>(cols, src, n_cols, n, lo, tw_end);
+        if (k == 9) return launch_a_ext<9, EXT, 15>(cols, src, n_cols, n, lo, tw_end);
+        return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+    }
     switch (k) {
         case 2: return launch_a_ext<2, EXT>(cols, src, n_cols, n, lo, tw_end);
         case 3: return launch_a_ext<3, EXT>(cols, src, n_cols, n, lo, tw_end);
@@ -555,6 +577,14 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         if (ps.k == 9) return launch_a<INV, 9, 13>(cols, n_cols, n, ps.lo, tw_end, scale);
         return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
     }
+    if (logta == 15) {          // the 128 KiB tile (two virtual lanes per lane): 10 layers on 128-byte rows, 9 on 256-byte rows
+        switch (ps.k) {
+            case 8: return launch_a<INV, 8, 15>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 9: return launch_a<INV, 9, 15>(cols, n_cols, n, ps.lo, tw_end, scale);
+            case 10: return launch_a<INV, 10, 15>(cols, n_cols, n, ps.lo, tw_end, scale);
+            default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+        }
+    }
     if (logta != 14) return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
     switch (ps.k) {
         case 1: return launch_a<INV, 1>(cols, n_cols, n, ps.lo, tw_end, scale);
@@ -569,6 +599,37 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         case 10: return launch_a<INV, 10>(cols, n_cols, n, ps.lo, tw_end, scale);
         default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
     }
+}
+
+// bottom tile, strided-pass layer limit and strided tile of an in-place transform of n_cols columns of 2^n words (n >= 13)
+void choose_plan(u32 n, size_t n_cols, u32 &kb, u32 &ka_max, u32 &logta) {
+    Context &c = ctx();
+    const PlanShape shape = default_shape(n, n_cols);
+    kb = shape.kb; ka_max = shape.ka_max;
+    const Knobs &kn = knobs();
+    if (kn.cfft_kb) kb = (u32)kn.cfft_kb;           // experiments build only: bottom-pass size, strided-pass limit
+    if (kn.cfft_ka) ka_max = (u32)kn.cfft_ka;
+    logta = shape.logta;
+    if (n > kb && n >= kLogTileA && !kn.cfft_kb && !kn.cfft_ka) {     // n = 13 (and 14) is one bottom pass whatever the column count
+        // Few columns: the default tiles (2^13 contiguous, 2^14 strided) give 2^(n-13) x cols and 2^(n-14) x cols workgroups;
+        // below ~2 per CU pick the split with the most workgroups in its emptier pass (ties: the larger tiles).
+        // n = 20, one column: 12 + 8 layers on 2^12-word tiles = 256 + 256 workgroups instead of 128 + 64.
+        const size_t want = (size_t)2 * (size_t)c.n_cus;
+        if ((((size_t)1 << (n - kLogTileA)) * n_cols) < want && n - 13 <= ka_max) {
+            size_t best = 0;
+            for (u32 tb = 13; tb >= 11; tb--) {
+                const u32 k = n - tb;
+                if (k < 1 || k > ka_max) continue;        // one strided pass
+                const u32 ta = k <= 8 ? 12u : (k == 9 ? 13u : 14u);
+                if (ta > n) continue;
+                size_t wa = ((size_t)1 << (n - ta)) * n_cols, wb = ((size_t)1 << (n - tb)) * n_cols;
+                size_t score = wa < wb ? wa : wb;
+                if (score > want) score = want;
+                if (score > best) { best = score; kb = tb; logta = ta; }
+            }
+        }
+    }
+    if (kn.cfft_logta) logta = (u32)kn.cfft_logta;   // experiments
 }
 
 template <bool INV>
@@ -604,31 +665,9 @@ int cfft(u32 *const *cols, size_t n_cols, u32 n, u32 half_initial, const u32 *tw
     if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
     if (tw_log > 31 || ((size_t)1 << (n - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
     Pass passes[8];
-    u32 kb = default_bottom_log(n), ka_max = kMaxKA;
+    u32 kb, ka_max, logta;
+    choose_plan(n, n_cols, kb, ka_max, logta);
     const Knobs &kn = knobs();
-    if (kn.cfft_kb) kb = (u32)kn.cfft_kb;           // experiments build only: bottom-pass size, strided-pass limit
-    if (kn.cfft_ka) ka_max = (u32)kn.cfft_ka;
-    u32 logta = kLogTileA;
-    if (n > kb && n >= kLogTileA && !kn.cfft_kb && !kn.cfft_ka) {     // n = 13 (and 14) is one bottom pass whatever the column count
-        // Few columns: the default tiles (2^13 contiguous, 2^14 strided) give 2^(n-13) x cols and 2^(n-14) x cols workgroups;
-        // below ~2 per CU pick the split with the most workgroups in its emptier pass (ties: the larger tiles).
-        // n = 20, one column: 12 + 8 layers on 2^12-word tiles = 256 + 256 workgroups instead of 128 + 64.
-        const size_t want = (size_t)2 * (size_t)c.n_cus;
-        if ((((size_t)1 << (n - kLogTileA)) * n_cols) < want && n - 13 <= ka_max) {
-            size_t best = 0;
-            for (u32 tb = 13; tb >= 11; tb--) {
-                const u32 k = n - tb;
-                if (k < 1 || k > ka_max) continue;        // one strided pass
-                const u32 ta = k <= 8 ? 12u : (k == 9 ? 13u : 14u);
-                if (ta > n) continue;
-                size_t wa = ((size_t)1 << (n - ta)) * n_cols, wb = ((size_t)1 << (n - tb)) * n_cols;
-                size_t score = wa < wb ? wa : wb;
-                if (score > want) score = want;
-                if (score > best) { best = score; kb = tb; logta = ta; }
-            }
-        }
-    }
-    if (kn.cfft_logta) logta = (u32)kn.cfft_logta;   // experiments
     int np = n >= kMaxLogTileB ? plan_passes(n, passes, kb, ka_max, logta) : plan_passes(n, passes);
     for (size_t i = 0; i < n_cols; i++)
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: columns must be 16-byte aligned");
@@ -676,6 +715,18 @@ int tstwo_cfft_interpolate(u32 *const *cols, size_t n_cols, u32 log_size, u32 ha
     return cfft<true>(cols, n_cols, log_size, half_initial, itw, tw_log);
 }
 
+int tstwo_cfft_plan_passes(u32 log_size, size_t n_cols, u32 *n_passes) {
+    TSTWO_REQUIRE_READY();          // (the planner asks the context for the CU count)
+    if (!n_passes) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null output");
+    if (log_size == 0 || log_size > kMaxLogSize) return set_error(TSTWO_ERR_BAD_ARG, "cfft: log_size out of range");
+    if (log_size < kMaxLogTileB) { *n_passes = 1; return TSTWO_OK; }
+    Pass passes[8];
+    u32 kb, ka_max, logta;
+    choose_plan(log_size, n_cols, kb, ka_max, logta);
+    *n_passes = (u32)plan_passes(log_size, passes, kb, ka_max, logta);
+    return TSTWO_OK;
+}
+
 // Out-of-place interpolation: src[i] (evaluations, left untouched) -> dst[i] (coefficients).  On the tiled path the first
 // (bottom) pass reads src and writes dst, so the clone the value-semantics API needs costs no extra pass over HBM.
 int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_cols, u32 log_size, u32 half_initial, const u32 *itw, u32 tw_log) {
@@ -694,8 +745,8 @@ int tstwo_cfft_interpolate_to(const u32 *const *src, u32 *const *dst, size_t n_c
         if (((uintptr_t)itw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
         Context &c = ctx();
         Pass passes[8];
-        const u32 kb = default_bottom_log(log_size);
-        const int np = plan_passes(log_size, passes, kb);
+        const int np = plan_default(log_size, n_cols, passes);
+        const u32 kb = passes[0].k;
         const u32 *tw_end = itw + ((size_t)1 << tw_log);
         const u32 n_inv = host::inv((1u << log_size) % M31_P);
         // bottom pass, out of place
@@ -749,7 +800,7 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
     int np = 0;
     const Knobs &kn = knobs();
     const bool tiled = log_size >= kMaxLogTileB && log_size <= kMaxLogSize && !kn.cfft_generic && !kn.cfft_kb && !kn.cfft_ka && !kn.cfft_no_fused_extend;
-    if (tiled) np = plan_passes(log_size, passes, log_size == 14 ? kMaxLogTileB : default_bottom_log(log_size));   // (n = 14: 13 + 1 keeps the fused extension)
+    if (tiled) np = log_size == 14 ? plan_passes(log_size, passes, kMaxLogTileB) : plan_default(log_size, n_cols, passes);   // (n = 14: 13 + 1 keeps the fused extension)
     if (tiled && np >= 2 && (ext == 1 || ext == 2) && passes[np - 1].k >= 2) {
         if (!tw) return set_error(TSTWO_ERR_BAD_ARG, "cfft: null twiddle buffer");
         if (tw_log > 31 || ((size_t)1 << (log_size - 1)) > ((size_t)1 << tw_log)) return set_error(TSTWO_ERR_TWIDDLES, "Not enough twiddles!");
@@ -758,8 +809,8 @@ int tstwo_cfft_evaluate_extended(const u32 *const *polys, u32 log_poly, u32 *con
         if (((uintptr_t)tw) & 15) return set_error(TSTWO_ERR_BAD_ARG, "cfft: twiddle buffer must be 16-byte aligned");
         const u32 *tw_end = tw + ((size_t)1 << tw_log);
         const Pass &top = passes[np - 1];
-        int rc = ext == 1 ? launch_a_ext_k<1>(top.k, out, polys, n_cols, log_size, top.lo, tw_end)
-                          : launch_a_ext_k<2>(top.k, out, polys, n_cols, log_size, top.lo, tw_end);
+        int rc = ext == 1 ? launch_a_ext_k<1>(top.k, top.c + top.k, out, polys, n_cols, log_size, top.lo, tw_end)
+                          : launch_a_ext_k<2>(top.k, top.c + top.k, out, polys, n_cols, log_size, top.lo, tw_end);
         if (rc) return rc;
         for (int s = np - 2; s >= 0; s--) {
             rc = launch_fast<false>(out, n_cols, log_size, passes[s], tw_end, 0);

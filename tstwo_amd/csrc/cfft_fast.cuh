@@ -334,24 +334,35 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), TSTWO_B_WAVES) k_cfft_b(ColPt
 }
 
 // ------------------------------------------------------------------------------------------------
-// Strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^C words (C = 14 - K), 1024 lanes.
+// Strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^C words (C = LOGT - K).
 // EXT > 0 (forward only, the pass that holds the transform's top layers): the input is a polynomial of log size
 // n - EXT in its own buffers (`src`), zero-extended to log size n on the fly.  The top EXT layers of a zero-padded input
 // only replicate (butterfly(a, 0, t) = (a, a)), so the quarter-tile vectors a lane needs are copies of each other:
 // they are loaded once from the small polynomial, the replicated layers are skipped, and the result goes to `cols`.
-// LOGT (12..14) = log2 of the tile: 2^(LOGT-4) lanes.  14 is the default; the smaller tiles exist for transforms of few
-// columns, where 2^(n-14) tiles would leave most of the 256 CUs without a workgroup.
+// LOGT (12..15) = log2 of the tile.  14 (1024 lanes x 16 words) is the default; the smaller tiles exist for transforms of few
+// columns, where 2^(n-14) tiles would leave most of the 256 CUs without a workgroup.  LOGT = 15 is the 128 KiB tile: still 1024
+// lanes (the workgroup limit) and still one workgroup per CU, every lane working as V = 2 "virtual lanes" of 16 words each, one
+// after the other inside every stage — the same stage code, twice the work between two barriers, twice the bytes in flight per
+// CU — so that a 10-layer pass keeps 128-byte rows (n = 24 = 14 + 10: two passes over HBM instead of three) and a 9-layer pass
+// has 256-byte rows.
 #ifdef TSTWO_A_WAVES          // experiments: minimum waves per SIMD asked of the strided pass (8 = two 1024-lane workgroups per CU)
-#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__(1 << (LOGT - 4), TSTWO_A_WAVES)
+#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__((LOGT) == 15 ? 1024 : 1 << ((LOGT) - 4), TSTWO_A_WAVES)
 #else
-#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__(1 << (LOGT - 4))
+#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__((LOGT) == 15 ? 1024 : 1 << ((LOGT) - 4))
 #endif
 template <bool INV, int K, int EXT = 0, int LOGT = 14>
 __global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EXT>::type src, u32 n_cols, u32 total_items, u32 n,
                                                 u32 lo, const u32 *__restrict__ tw_end, u32 scale) {
     static_assert(EXT == 0 || (!INV && K >= 2 && EXT <= 2), "fused extension: forward pass with two register layers");
-    static_assert(LOGT >= 12 && LOGT <= 14 && LOGT - K >= 4, "strided tile: rows of at least 16 words");
-    constexpr int THREADS = 1 << (LOGT - 4), C = LOGT - K;
+    static_assert(LOGT >= 12 && LOGT <= 15 && LOGT - K >= 4, "strided tile: rows of at least 16 words");
+    constexpr int V = LOGT == 15 ? 2 : 1;      // virtual lanes (16 words each) per lane
+#ifdef TSTWO_A_SB
+    constexpr bool SB = true;
+#else
+    constexpr bool SB = LOGT == 15;            // scalar-base addressing (below)
+#endif
+    constexpr int VT = 1 << (LOGT - 4);        // virtual lanes per tile
+    constexpr int THREADS = VT / V, C = LOGT - K;
     constexpr u32 T = 1u << LOGT, QT = T / 4;
     constexpr int F = K >= 2 ? 2 : 1;          // layers fused into the load / store
     constexpr int R = K - F;                   // layers run as LDS stages
@@ -376,6 +387,13 @@ __global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EX
     const size_t base = ((size_t)hi << (lo + K)) | ((size_t)mid << C);
     // tile-relative word offset: < 2^(lo + K) <= 2^30 words (log_size <= 30), so 32 bits hold it
     auto goff = [&](u32 e) -> u32 { return ((e >> C) << lo) + (e & ((1u << C) - 1u)); };
+    // Scalar-base addressing (SB; the 2^15 tile, and -DTSTWO_A_SB for A/B timing of the others).  A word offset of this kernel is
+    // goff(e) with e a bit-rearrangement of (virtual lane id, g, m): every bit of the inputs lands on its own output bit, so
+    //   goff(e(t + c0, m)) = goff(e(t, 0)) + goff(e(c0, m))        (c0 = v THREADS + g VT: compile-time, above t's bits)
+    // — ONE lane offset per access pattern (loop-invariant, a single VGPR) plus a wave-uniform term that goes into the scalar
+    // base of `global_load/store v_off, s[base]`.  The pointer form costs a 64-bit VGPR address (and the 64-bit adds that make
+    // it) per access: 32 of them per virtual lane in the final stage, which is what spilled at 32 words per lane.
+    const u32 lane4 = goff(4 * t);                                   // quarter-tile vectors: word 4 t of each quarter
 
     // Twiddle staging (LDS heap for the stage layers, ta / tb for the register layers).  Called AFTER the first tile's loads
     // have been issued: the heap fill waits for its own global loads, and a memory round trip costs ~2300 cycles here
@@ -402,29 +420,39 @@ __global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EX
         }
         ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
     };
-    // element offsets of this lane's 16 words in the final-stage layout (R > 0)
-    auto e_final = [&](u32 tt, int g, int m) -> u32 {
-        const u32 gid = tt + (u32)g * THREADS;
+    // element offsets of a virtual lane's 16 words in the final-stage layout (R > 0)
+    auto e_final = [&](u32 vt, int g, int m) -> u32 {
+        const u32 gid = vt + (u32)g * VT;
         const u32 low = gid & ((1u << C) - 1u), high = gid >> C;
         return (high << (C + G2)) | ((u32)m << C) | low;
     };
+    const u32 lane_f = goff(e_final(t, 0, 0));                       // SB: lane part of the final-stage offsets
+    auto u_final = [&](int v, int g, int m) -> u32 { return goff(e_final((u32)v * THREADS, g, m)); };    // SB: uniform part
+    auto u_quarter = [&](int v, int j) -> u32 { return goff(4u * (u32)v * THREADS + (u32)j * QT); };
 
     if constexpr (!INV || R == 0) {
         // (column accesses in pointer form here: with the base + 32-bit-offset form of the inverse branch this kernel is 4 us
         // faster and the bottom pass that follows it 17 us slower — same bottom-pass code, measured twice on one box)
-        // forward (and the LDS-free case): four quarter-tile vectors per lane
-        uint4 pf[4];
-        // loads of the lane's four quarter-tile vectors (j = 2 * top bit + second bit); with EXT the vectors that differ
+        // forward (and the LDS-free case): four quarter-tile vectors per virtual lane
+        uint4 pf[V][4];
+        // loads of a virtual lane's four quarter-tile vectors (j = 2 * top bit + second bit); with EXT the vectors that differ
         // only in replicated bits are one load from the small polynomial
         auto load_tile = [&](const u32 *__restrict__ d) {
-            if constexpr (EXT == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) pf[j] = gload4(d + goff(4 * t + j * QT));
-            } else if constexpr (EXT == 1) {
-                pf[0] = gload4(d + goff(4 * t));
-                pf[1] = gload4(d + goff(4 * t + QT));
-            } else {
-                pf[0] = gload4(d + goff(4 * t));
+            for (int v = 0; v < V; v++) {
+                const u32 vt = t + (u32)v * THREADS;
+                if constexpr (SB) {
+#pragma unroll
+                    for (int j = 0; j < (EXT == 0 ? 4 : EXT == 1 ? 2 : 1); j++) pf[v][j] = gload4(d + u_quarter(v, j), lane4);
+                } else if constexpr (EXT == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pf[v][j] = gload4(d + goff(4 * vt + j * QT));
+                } else if constexpr (EXT == 1) {
+                    pf[v][0] = gload4(d + goff(4 * vt));
+                    pf[v][1] = gload4(d + goff(4 * vt + QT));
+                } else {
+                    pf[v][0] = gload4(d + goff(4 * vt));
+                }
             }
         };
         auto src_of = [&](u32 col) -> const u32 * {
@@ -438,64 +466,85 @@ __global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EX
             const u32 *__restrict__ next = src_of(min(col + 1, col1 - 1));
             u32 tt = t;
             asm volatile("" : "+v"(tt));     // opaque per iteration: keeps the 16 scatter addresses out of loop-invariant registers
-            if constexpr (EXT == 0) {
-                top_layers<INV, F == 2>(pf, ta, tb0, tb1);
-            } else if constexpr (EXT == 1) {     // top layer replicates: x2 = x0, x3 = x1; second layer is real
-                pf[2] = pf[0]; pf[3] = pf[1];
-                quarter_layer_second<false, true>(pf, tb0, tb1);
-            } else {                              // both register layers replicate
-                pf[1] = pf[0]; pf[2] = pf[0]; pf[3] = pf[0];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                if constexpr (EXT == 0) {
+                    top_layers<INV, F == 2>(pf[v], ta, tb0, tb1);
+                } else if constexpr (EXT == 1) {     // top layer replicates: x2 = x0, x3 = x1; second layer is real
+                    pf[v][2] = pf[v][0]; pf[v][3] = pf[v][1];
+                    quarter_layer_second<false, true>(pf[v], tb0, tb1);
+                } else {                              // both register layers replicate
+                    pf[v][1] = pf[v][0]; pf[v][2] = pf[v][0]; pf[v][3] = pf[v][0];
+                }
             }
             if constexpr (R == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    uint4 x = pf[j];
-                    if (INV && scale) x = scale4(x, scale);
-                    gstore4(data + goff(4 * t + j * QT), x);
-                }
+                for (int v = 0; v < V; v++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint4 x = pf[v][j];
+                        if (INV && scale) x = scale4(x, scale);
+                        if constexpr (SB) gstore4(data + u_quarter(v, j), lane4, x);
+                        else gstore4(data + goff(4 * (t + (u32)v * THREADS) + j * QT), x);
+                    }
                 load_tile(next);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
-                    p[0] = pf[j].x; p[1] = pf[j].y; p[2] = pf[j].z; p[3] = pf[j].w;
-                }
+                for (int v = 0; v < V; v++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        // pad(4 (t + v THREADS)) = pad(4 t) + v (4 THREADS + THREADS / 8): 4 THREADS is a multiple of 32 above 4 t's bits
+                        u32 *p = lds + pad(4 * t) + v * (4 * THREADS + THREADS / 8) + j * (QT + QT / 32);
+                        p[0] = pf[v][j].x; p[1] = pf[v][j].y; p[2] = pf[v][j].z; p[3] = pf[v][j].w;
+                    }
                 lds_barrier();
                 load_tile(next);
                 if constexpr (G1 > 0) {
-                    lds_stage<G1, C + 4, LOGT, THREADS, false>(lds, twl, t);
+#pragma unroll
+                    for (int v = 0; v < V; v++) lds_stage<G1, C + 4, LOGT, VT, false>(lds, twl, t + (u32)v * THREADS);
                     lds_barrier();
                 }
                 // final stage: butterflies, then straight to HBM (rows of 2^C words: >= 128 B per half-wave)
                 {
+                    // (virtual lanes one after the other: 16 tile words live at a time beside the 16 V words of the prefetch)
                     constexpr int NG = 16 >> G2;
-                    u32 v[NG][1 << G2], high[NG];
 #pragma unroll
-                    for (int g = 0; g < NG; g++) {
-                        high[g] = (t + (u32)g * THREADS) >> C;
+                    for (int v = 0; v < V; v++) {
+                        u32 w[NG][1 << G2], high[NG];
 #pragma unroll
-                        for (int m = 0; m < (1 << G2); m++) v[g][m] = lds[pad(e_final(tt, g, 0)) + off<C>(m)];
+                        for (int g = 0; g < NG; g++) {
+                            high[g] = (t + (u32)v * THREADS + (u32)g * VT) >> C;
+#pragma unroll
+                            for (int m = 0; m < (1 << G2); m++) w[g][m] = lds[pad(e_final(tt + (u32)v * THREADS, g, 0)) + off<C>(m)];
+                        }
+                        if (v == V - 1) lds_barrier();   // last access to the tile in LDS: the next column may overwrite it while this stage computes
+                        groups_layers<G2, NG, C, LOGT, false>(w, twl, high);
+#pragma unroll
+                        for (int g = 0; g < NG; g++)
+#pragma unroll
+                            for (int m = 0; m < (1 << G2); m++) {
+                                if constexpr (SB) gstore1(data + u_final(v, g, m), lane_f, w[g][m]);
+                                else gstore1(data + goff(e_final(tt + (u32)v * THREADS, g, m)), w[g][m]);
+                            }
                     }
-                    lds_barrier();   // last access to the tile in LDS: the next column may overwrite it while this stage computes
-                    groups_layers<G2, NG, C, LOGT, false>(v, twl, high);
-#pragma unroll
-                    for (int g = 0; g < NG; g++)
-#pragma unroll
-                        for (int m = 0; m < (1 << G2); m++) gstore1(data + goff(e_final(tt, g, m)), v[g][m]);
                 }
             }
         }
         if constexpr (R > 0) lds_barrier();      // the final stage read the twiddle heap: the next run restages it
     } else {
-        // inverse with LDS stages: the lane's 16 words arrive in the first-stage layout
-        u32 pfs[16];
+        // inverse with LDS stages: a virtual lane's 16 words arrive in the first-stage layout
+        constexpr int NG = 16 >> G2;
+        u32 pfs[V][16];
         {
             const u32 tt = t;
             const u32 *__restrict__ d = colp_u(cols, col0) + base;
 #pragma unroll
-            for (int g = 0; g < (16 >> G2); g++)
+            for (int v = 0; v < V; v++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(d, goff(e_final(tt, g, m)));
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int m = 0; m < (1 << G2); m++)
+                        pfs[v][g * (1 << G2) + m] = SB ? gload1(d + u_final(v, g, m), lane_f) : gload1(d, goff(e_final(tt + (u32)v * THREADS, g, m)));
         }
         stage_twiddles();
         lds_barrier();       // the inverse reads the heap in its first stage, before any other barrier
@@ -504,41 +553,51 @@ __global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EX
             const u32 *__restrict__ next = colp_u(cols, min(col + 1, col1 - 1)) + base;
             u32 tt = t;
             asm volatile("" : "+v"(tt));
-            {
-                constexpr int NG = 16 >> G2;
-                u32 v[NG][1 << G2], high[NG];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                u32 w[NG][1 << G2], high[NG];
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
-                    high[g] = (t + (u32)g * THREADS) >> C;
+                    high[g] = (t + (u32)v * THREADS + (u32)g * VT) >> C;
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) v[g][m] = pfs[g * (1 << G2) + m];
+                    for (int m = 0; m < (1 << G2); m++) w[g][m] = pfs[v][g * (1 << G2) + m];
                 }
-                groups_layers<G2, NG, C, LOGT, true>(v, twl, high);
+                groups_layers<G2, NG, C, LOGT, true>(w, twl, high);
 #pragma unroll
                 for (int g = 0; g < NG; g++)
 #pragma unroll
-                    for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(tt, g, 0)) + off<C>(m)] = v[g][m];
+                    for (int m = 0; m < (1 << G2); m++) lds[pad(e_final(tt + (u32)v * THREADS, g, 0)) + off<C>(m)] = w[g][m];
             }
             lds_barrier();
 #pragma unroll
-            for (int g = 0; g < (16 >> G2); g++)
+            for (int v = 0; v < V; v++)
 #pragma unroll
-                for (int m = 0; m < (1 << G2); m++) pfs[g * (1 << G2) + m] = gload1(next, goff(e_final(tt, g, m)));
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int m = 0; m < (1 << G2); m++)
+                        pfs[v][g * (1 << G2) + m] = SB ? gload1(next + u_final(v, g, m), lane_f) : gload1(next, goff(e_final(tt + (u32)v * THREADS, g, m)));
             if constexpr (G1 > 0) {
-                lds_stage<G1, C + 4, LOGT, THREADS, true>(lds, twl, t);
+#pragma unroll
+                for (int v = 0; v < V; v++) lds_stage<G1, C + 4, LOGT, VT, true>(lds, twl, t + (u32)v * THREADS);
                 lds_barrier();
             }
-            uint4 x[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32 *p = lds + pad(4 * t) + j * (QT + QT / 32);
-                x[j] = make_uint4(p[0], p[1], p[2], p[3]);
+            for (int v = 0; v < V; v++) {
+                uint4 x[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u32 *p = lds + pad(4 * t) + v * (4 * THREADS + THREADS / 8) + j * (QT + QT / 32);
+                    x[j] = make_uint4(p[0], p[1], p[2], p[3]);
+                }
+                if (v == V - 1) lds_barrier();       // last LDS access of this column
+                top_layers<true, F == 2>(x, ta, tb0, tb1);
+                if (scale) scale16(x, scale);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if constexpr (SB) gstore4(data + u_quarter(v, j), lane4, x[j]);
+                    else gstore4(data, goff(4 * (t + (u32)v * THREADS) + j * QT), x[j]);
+                }
             }
-            lds_barrier();       // last LDS access of this column
-            top_layers<true, F == 2>(x, ta, tb0, tb1);
-            if (scale) scale16(x, scale);
-#pragma unroll
-            for (int j = 0; j < 4; j++) gstore4(data, goff(4 * t + j * QT), x[j]);
         }
     }
     }   // runs of one tile

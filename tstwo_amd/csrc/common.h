@@ -61,6 +61,7 @@ struct Knobs {
     int merkle_subtree = 2;            // TSTWO_MERKLE_SUBTREE: column-free layers per launch of the in-lane subtree kernel (0, 2-4)
     bool merkle_generic = false, merkle_up_onelane = false, merkle_up_smallwg = false, merkle_up_narrow_first = false;
     bool merkle_no_fused_leaf4 = false, merkle_no_batch = false;
+    bool merkle_subtree_lane_stride = false;   // TSTWO_MERKLE_SUBTREE_LANE_STRIDE: round 3's k_merkle_subtree<2> instead of the coalesced k_merkle_subtree2c (A/B)
     // fri.hip
     bool fri_no_tail = false, fri_no_fold_fusion = false;   // TSTWO_FRI_NO_TAIL / TSTWO_FRI_NO_FOLD_FUSION
     int fold_cap = 64;                 // TSTWO_FOLD_CAP: workgroups per CU of the fold kernels

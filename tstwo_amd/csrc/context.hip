@@ -38,6 +38,7 @@ static Knobs read_knobs() {
     k.merkle_generic = on("TSTWO_MERKLE_GENERIC"); k.merkle_up_onelane = on("TSTWO_MERKLE_UP_ONELANE");
     k.merkle_up_smallwg = on("TSTWO_MERKLE_UP_SMALLWG"); k.merkle_up_narrow_first = on("TSTWO_MERKLE_UP_NARROW_FIRST");
     k.merkle_no_fused_leaf4 = on("TSTWO_MERKLE_NO_FUSED_LEAF4"); k.merkle_no_batch = on("TSTWO_MERKLE_NO_BATCH");
+    k.merkle_subtree_lane_stride = on("TSTWO_MERKLE_SUBTREE_LANE_STRIDE");
     k.fri_no_tail = on("TSTWO_FRI_NO_TAIL"); k.fri_no_fold_fusion = on("TSTWO_FRI_NO_FOLD_FUSION");
     k.fold_cap = num("TSTWO_FOLD_CAP", 64); k.fold1 = on("TSTWO_FOLD1");
     k.qinv_k = num("TSTWO_QINV_K", 0); k.qinv_montgomery = on("TSTWO_QINV_MONTGOMERY");

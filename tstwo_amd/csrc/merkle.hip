@@ -422,6 +422,72 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(TreeSet ts, u32 log_chil
     }
 }
 
+// The two-level subtree with every global access a 1 KiB-contiguous wave access (round 4).  In k_merkle_subtree<2> a lane reads its
+// four children as eight 16-byte loads at a 128-byte lane stride and writes its digests at 64- and 32-byte lane strides: every
+// instruction touches 64 lines a piece each, the pieces of a line arrive a compression apart, and with 32 waves per CU the lines
+// do not survive in the caches in between — the counters showed 1.31 x the child bytes fetched and 1.16-1.24 x the digest bytes
+// written (profiles/r03_cfft_pmc.json), on launches that move 4.3 TB/s.  Here a wave loads its 256 children as eight 1 KiB rows,
+// transposes them to "lane owns 128 consecutive bytes" through its OWN 4.5 KiB of LDS (two halves of 4 KiB, one pad slot per
+// 8 chunks: conflict-free both ways; wave-local, so no barrier — the LDS executes a wave's instructions in order), and stores
+// the 128 + 64 digests it produced the same way, all six store instructions back to back at the end of the wave.
+// Needs the top layer (2^(log_child-2) nodes) to be a multiple of 256 nodes: the host falls back to k_merkle_subtree<2> otherwise.
+__device__ __forceinline__ u32 xslot(u32 chunk) { return chunk + (chunk >> 3); }
+__global__ void __launch_bounds__(256) k_merkle_subtree2c(TreeSet ts, u32 log_child) {
+    __shared__ uint4 xch[4][288];                       // per wave: 256 chunks of 16 bytes + 32 pad slots
+    uint4 *__restrict__ layers = ts.t[blockIdx.y];
+    const u32 lane = threadIdx.x & 63u;
+    uint4 *x = xch[threadIdx.x >> 6];
+    const size_t top0 = (size_t)blockIdx.x * 256u + (threadIdx.x & ~63u);        // the wave's first node of layer log_child - 2
+    const u32 *cbase = (const u32 *)(layers + 2 * ((((size_t)1 << log_child) - 1) + 4 * top0));
+    uint4 in[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) in[k] = gload4(cbase, 4u * (64u * k + lane));
+    Digest ch[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[xslot(64u * k + lane)] = in[4 * h + k];
+        asm volatile("" ::: "memory");
+        if ((lane >> 5) == (u32)h) {                    // chunks 8 l .. 8 l + 7 of this half belong to lane 32 h + l
+            const uint4 *mine = x + 9u * (lane & 31u);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 a = mine[2 * j], b = mine[2 * j + 1];
+                ch[j] = {{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    const Digest l = hash_pair(ch[0], ch[1]);
+    const Digest r = hash_pair(ch[2], ch[3]);
+    const Digest top = hash_pair(l, r);
+    // layer log_child - 1: the wave's 128 digests = 256 chunks; lane's chunks 4 lane .. 4 lane + 3
+    {
+        uint4 *mine = x + xslot(4u * lane);             // 4 lane + j, j < 4, stays inside one group of 8: same pad
+        mine[0] = make_uint4(l.w[0], l.w[1], l.w[2], l.w[3]); mine[1] = make_uint4(l.w[4], l.w[5], l.w[6], l.w[7]);
+        mine[2] = make_uint4(r.w[0], r.w[1], r.w[2], r.w[3]); mine[3] = make_uint4(r.w[4], r.w[5], r.w[6], r.w[7]);
+    }
+    asm volatile("" ::: "memory");
+    uint4 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = x[xslot(64u * k + lane)];
+    asm volatile("" ::: "memory");
+    {
+        uint4 *mine = x + xslot(2u * lane);
+        mine[0] = make_uint4(top.w[0], top.w[1], top.w[2], top.w[3]); mine[1] = make_uint4(top.w[4], top.w[5], top.w[6], top.w[7]);
+    }
+    asm volatile("" ::: "memory");
+    uint4 o2[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) o2[k] = x[xslot(64u * k + lane)];
+    u32 *mid = (u32 *)(layers + 2 * ((((size_t)1 << (log_child - 1)) - 1) + 2 * top0));
+    u32 *up = (u32 *)(layers + 2 * ((((size_t)1 << (log_child - 2)) - 1) + top0));
+#pragma unroll
+    for (int k = 0; k < 4; k++) gstore4(mid, 4u * (64u * k + lane), o[k]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) gstore4(up, 4u * (64u * k + lane), o2[k]);
+}
+
 // Several column-free levels per launch: a workgroup of WG lanes owns 2*WG consecutive nodes of layer `log_child`
 // and produces the WG, WG/2, ... nodes above them (LEVELS levels), exchanging digests through LDS.  Every level is
 // still written to its place in the layers buffer (MerkleProver keeps all layers, vcs/prover.ts:24-29).
@@ -1437,7 +1503,10 @@ int tstwo_merkle_commit(const u32 *const *cols, const u32 *log_sizes, size_t n_c
                 TreeSet one = {};
                 one.t[0] = (uint4 *)layers;
                 switch (run) {
-                    case 2: hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1); break;
+                    case 2:
+                        if (tops % 256 == 0 && !knobs().merkle_subtree_lane_stride) hipLaunchKernelGGL(k_merkle_subtree2c, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1);
+                        else hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1);
+                        break;
                     case 3: hipLaunchKernelGGL(k_merkle_subtree<3>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1); break;
                     default: hipLaunchKernelGGL(k_merkle_subtree<4>, dim3(blocks), dim3(256), 0, c.stream, one, (u32)lg + 1); break;
                 }
@@ -1516,7 +1585,9 @@ int tstwo_merkle_commit_many(const tstwo_commit_request *reqs, size_t n_trees, u
         // quad-lane levels: the launch sequence of tstwo_merkle_commit for a tree whose columns all sit on the leaf layer
         int cur = (int)lg - 1;
         while (cur - 1 >= up_log) {
-            hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(ceil_div((size_t)1 << (cur - 1), 256), (unsigned)n_trees), dim3(256), 0, c.stream, ts, (u32)cur + 1);
+            const size_t tops = (size_t)1 << (cur - 1);
+            if (tops % 256 == 0 && !knobs().merkle_subtree_lane_stride) hipLaunchKernelGGL(k_merkle_subtree2c, dim3((unsigned)(tops / 256), (unsigned)n_trees), dim3(256), 0, c.stream, ts, (u32)cur + 1);
+            else hipLaunchKernelGGL(k_merkle_subtree<2>, dim3(ceil_div(tops, 256), (unsigned)n_trees), dim3(256), 0, c.stream, ts, (u32)cur + 1);
             cur -= 2;
         }
         if (cur >= up_log) {
