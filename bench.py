@@ -582,6 +582,11 @@ def main():
             from bench_configs import run_configs
             del dev_cols[:], layers[:]
             out["configs"] = run_configs(reps=10, no_cpu=args.no_cpu)      # BASELINE configs 1-4, same JSON line
+            # ... and the callers either side of the hot path at config 5's size (pcs/prover.ts:26-252): the trace committed as
+            # 8 trees on the blown-up domain, and an opening proof over it (tools/bench_config5_callers.py)
+            if n == LOG_SIZE and total_cols == TOTAL_COLS and args.scaling == "strong":
+                from bench_config5_callers import run_config5_callers
+                out["configs"] += run_config5_callers(reps=3, total_cols=total_cols, n=n, tree_cols=tree_cols)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

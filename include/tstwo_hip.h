@@ -73,6 +73,27 @@ int tstwo_set_alloc_mode(int mode);
 /* The host buffer may be reused as soon as tstwo_upload returns; the copy itself is ordered on the stream (small
  * uploads travel through a page-locked ring without a host synchronisation, large ones synchronise). */
 int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes);
+/* Host hand-over beside the kernels — the boundary createBaseFieldColumn(data) crosses (backend/index.ts:20-31,
+ * backend/cpu/index.ts:85-90).  tstwo_upload is synchronous and, from pageable memory, staged by the runtime (35-39 GB/s on the
+ * MI355X box).  Page-locked memory makes a copy ONE DMA at link rate, and tstwo_upload_async issues it on the library's copy
+ * stream, beside the kernels of the main stream (upload of column group k+1 under the transform of group k):
+ *   tstwo_host_register / _unregister   page-lock (and unlock) a range of the CALLER's memory (a Uint32Array's backing store);
+ *   tstwo_host_alloc / _free            page-locked memory from the library (bun:ffi toArrayBuffer wraps it);
+ *   tstwo_upload_async(dst, src, n)     enqueue the copy and return.  It starts after everything enqueued on the main stream
+ *                                       BEFORE this call (a block tstwo_malloc has just recycled is no longer in use by then);
+ *                                       src must stay valid and unchanged until tstwo_upload_wait / tstwo_sync returns, dst must
+ *                                       not be freed before.  Pageable src works, at tstwo_upload's rate.  Refused during
+ *                                       graph capture;
+ *   tstwo_upload_fence()                everything enqueued on the main stream AFTER this call waits (on the device) for the
+ *                                       copies issued so far; the host does not block;
+ *   tstwo_upload_wait()                 the host blocks until the copies issued so far have landed. */
+int tstwo_host_register(void *host, size_t bytes);
+int tstwo_host_unregister(void *host);
+int tstwo_host_alloc(void **host, size_t bytes);
+int tstwo_host_free(void *host);
+int tstwo_upload_async(void *dev_dst, const void *host_src, size_t bytes);
+int tstwo_upload_fence(void);
+int tstwo_upload_wait(void);
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
 /* n_pieces small device buffers in one round trip: piece i = n_bytes[i] bytes (whole 4-byte aligned words) at srcs[i]; the pieces
  * land back to back in host_out.  Up to 256 KiB in all they are packed on the device into page-locked host memory and cost one

@@ -29,6 +29,13 @@ const lib = dlopen(process.env.TSTWO_HIP_LIB ?? "libtstwo_hip.so", {
   tstwo_malloc: { args: [P, u64], returns: i32 },
   tstwo_free: { args: [u64], returns: i32 },
   tstwo_upload: { args: [u64, P, u64], returns: i32 },
+  tstwo_host_register: { args: [P, u64], returns: i32 },
+  tstwo_host_unregister: { args: [P], returns: i32 },
+  tstwo_host_alloc: { args: [P, u64], returns: i32 },
+  tstwo_host_free: { args: [P], returns: i32 },
+  tstwo_upload_async: { args: [u64, P, u64], returns: i32 },
+  tstwo_upload_fence: { args: [], returns: i32 },
+  tstwo_upload_wait: { args: [], returns: i32 },
   tstwo_download: { args: [P, u64, u64], returns: i32 },
   tstwo_download_many: { args: [P, P, u64, P], returns: i32 },
   tstwo_copy: { args: [u64, u64, u64], returns: i32 },

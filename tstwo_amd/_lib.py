@@ -66,6 +66,13 @@ _SIGS = {
     "tstwo_trim": [],
     "tstwo_set_alloc_mode": [C.c_int],
     "tstwo_upload": [vp, vp, C.c_size_t],
+    "tstwo_host_register": [vp, C.c_size_t],
+    "tstwo_host_unregister": [vp],
+    "tstwo_host_alloc": [C.POINTER(vp), C.c_size_t],
+    "tstwo_host_free": [vp],
+    "tstwo_upload_async": [vp, vp, C.c_size_t],
+    "tstwo_upload_fence": [],
+    "tstwo_upload_wait": [],
     "tstwo_download": [vp, vp, C.c_size_t],
     "tstwo_download_many": [C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, vp],
     "tstwo_copy": [vp, vp, C.c_size_t],
@@ -142,7 +149,8 @@ _SIGS = {
 }
 ALLOC_POOL, ALLOC_DIRECT, ALLOC_ASYNC, ALLOC_POISON = 0, 1, 2, 0x10
 # c_void_p arguments above are DEVICE addresses, except these (host memory of any element type)
-HOST_VOID_ARGS = {"tstwo_upload": {1}, "tstwo_download": {0}, "tstwo_download_many": {3}}
+HOST_VOID_ARGS = {"tstwo_upload": {1}, "tstwo_download": {0}, "tstwo_download_many": {3}, "tstwo_host_register": {0}, "tstwo_host_unregister": {0},
+                  "tstwo_host_free": {0}, "tstwo_upload_async": {1}}
 # every symbol include/tstwo_hip.h declares (tests check the library exports all of them)
 EXPORTS = sorted(list(_SIGS) + ["tstwo_last_error", "tstwo_version", "tstwo_merkle_layers_bytes"])
 
@@ -223,6 +231,49 @@ def sync() -> None:
     call("tstwo_sync")
 
 
+def host_register(arr: np.ndarray) -> None:
+    """Page-lock the memory of a host array the caller owns (tstwo_host_register): uploads from it are one DMA at link rate."""
+    ensure_init()
+    call("tstwo_host_register", arr.ctypes.data_as(vp), arr.nbytes)
+
+
+def host_unregister(arr: np.ndarray) -> None:
+    call("tstwo_host_unregister", arr.ctypes.data_as(vp))
+
+
+def upload_fence() -> None:
+    call("tstwo_upload_fence")
+
+
+def upload_wait() -> None:
+    call("tstwo_upload_wait")
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from the library (tstwo_host_alloc / tstwo_host_free)."""
+
+    def __init__(self, count: int, dtype=np.uint32):
+        ensure_init()
+        dt = np.dtype(dtype)
+        p = vp()
+        call("tstwo_host_alloc", C.byref(p), count * dt.itemsize)
+        self._ptr = p.value
+        buf = (C.c_uint8 * (count * dt.itemsize)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=dt, count=count)
+
+    def free(self) -> None:
+        if self._ptr:
+            self.array = None
+            call("tstwo_host_free", vp(self._ptr))
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:          # noqa: BLE001 — interpreter shutdown
+            pass
+
+
 class DeviceBuffer:
     """An owned device allocation (tstwo_malloc / tstwo_free)."""
 
@@ -260,6 +311,12 @@ class DeviceBuffer:
         arr = np.ascontiguousarray(arr)
         assert offset + arr.nbytes <= self.nbytes
         call("tstwo_upload", vp(self.ptr + offset), arr.ctypes.data_as(vp), arr.nbytes)
+
+    def upload_async(self, arr: np.ndarray, offset: int = 0) -> None:
+        """tstwo_upload_async: the copy runs on the library's copy stream beside the kernels; `arr` (best: page-locked — PinnedArray
+        or host_register) must stay alive and unchanged until upload_wait() / sync()."""
+        assert arr.flags["C_CONTIGUOUS"] and offset + arr.nbytes <= self.nbytes
+        call("tstwo_upload_async", vp(self.ptr + offset), arr.ctypes.data_as(vp), arr.nbytes)
 
     def download(self, dtype=np.uint32, count: int | None = None, offset: int = 0) -> np.ndarray:
         dt = np.dtype(dtype)

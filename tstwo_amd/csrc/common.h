@@ -33,6 +33,10 @@ struct Context {
     hipEvent_t up_done[16] = {};      // recorded behind the copy that last used the slot
     bool up_busy[16] = {};
     int up_next = 0;
+    hipStream_t copy_stream = nullptr;   // tstwo_upload_async: host -> device copies beside the kernels of `stream`, fenced by the two events below
+    hipEvent_t copy_after = nullptr;     // recorded on `stream`, waited for by copy_stream: a copy never overtakes work enqueued before it
+    hipEvent_t copy_done = nullptr;      // recorded on copy_stream behind the last copy: tstwo_upload_fence makes `stream` wait for it
+    bool copy_pending = false;
 };
 constexpr size_t kPinnedBytes = 64 * 1024;
 constexpr size_t kResultBytes = 256 * 1024;

@@ -394,6 +394,12 @@ int tstwo_shutdown(void) {
     if (c.coltab) (void)hipFree(c.coltab);
     coltab_cache_reset();
     if (c.scratch) (void)hipFree(c.scratch);
+    if (c.copy_stream) {
+        (void)hipStreamSynchronize(c.copy_stream);
+        (void)hipEventDestroy(c.copy_after);
+        (void)hipEventDestroy(c.copy_done);
+        (void)hipStreamDestroy(c.copy_stream);
+    }
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = Context();
     return TSTWO_OK;
@@ -453,6 +459,10 @@ int tstwo_graph_destroy(void *graph_exec) {
 int tstwo_sync(void) {
     TSTWO_REQUIRE_READY();
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (g_ctx.copy_pending) {            // copies of tstwo_upload_async that nothing fenced: "everything the library was asked to do is done"
+        TSTWO_HIP(hipStreamSynchronize(g_ctx.copy_stream));
+        g_ctx.copy_pending = false;
+    }
     return TSTWO_OK;
 }
 
@@ -554,6 +564,70 @@ int tstwo_upload(void *dev_dst, const void *host_src, size_t bytes) {
     if (bytes <= kPinnedBytes) return small_h2d(dev_dst, host_src, bytes);
     TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, g_ctx.stream));
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
+    return TSTWO_OK;
+}
+// ---- Host hand-over beside the kernels (the boundary the TypeScript prover crosses: createBaseFieldColumn(data),
+// backend/index.ts:20-31, backend/cpu/index.ts:85-90).  tstwo_upload is synchronous and, from pageable memory, staged by the
+// runtime (34-39 GB/s measured: 19 steps' worth of time for the config-5 trace).  From page-locked memory — the caller's own
+// buffers registered with tstwo_host_register, or buffers from tstwo_host_alloc — a copy is one DMA at link rate, and issued on
+// the library's copy stream it runs BESIDE the kernels of the main stream: upload of column group k+1 under the transform of group k.
+// Ordering: a copy starts only after everything enqueued on the main stream BEFORE the tstwo_upload_async call (so a
+// destination block the allocator has just recycled is no longer in use), and nothing enqueued on the main stream after
+// tstwo_upload_fence() starts before the copies issued so far have landed.  The host never blocks in either; tstwo_upload_wait
+// blocks until the copies are done (the source may then be reused).
+int tstwo_host_register(void *host, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (!host || !bytes) return set_error(TSTWO_ERR_BAD_ARG, "host_register: null or empty range");
+    TSTWO_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return TSTWO_OK;
+}
+int tstwo_host_unregister(void *host) {
+    TSTWO_REQUIRE_READY();
+    if (!host) return set_error(TSTWO_ERR_BAD_ARG, "host_unregister: null pointer");
+    TSTWO_HIP(hipHostUnregister(host));
+    return TSTWO_OK;
+}
+int tstwo_host_alloc(void **host, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (!host) return set_error(TSTWO_ERR_BAD_ARG, "host_alloc: null output");
+    *host = nullptr;
+    TSTWO_HIP(hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault));
+    return TSTWO_OK;
+}
+int tstwo_host_free(void *host) {
+    TSTWO_REQUIRE_READY();
+    if (!host) return TSTWO_OK;
+    TSTWO_HIP(hipHostFree(host));
+    return TSTWO_OK;
+}
+int tstwo_upload_async(void *dev_dst, const void *host_src, size_t bytes) {
+    TSTWO_REQUIRE_READY();
+    if (bytes == 0) return TSTWO_OK;
+    TSTWO_REQUIRE_PTRS(dev_dst, host_src);
+    Context &c = g_ctx;
+    if (int rc = refuse_if_capturing(c.stream)) return rc;
+    if (!c.copy_stream) {
+        TSTWO_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+        TSTWO_HIP(hipEventCreateWithFlags(&c.copy_after, hipEventDisableTiming));
+        TSTWO_HIP(hipEventCreateWithFlags(&c.copy_done, hipEventDisableTiming));
+    }
+    TSTWO_HIP(hipEventRecord(c.copy_after, c.stream));
+    TSTWO_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_after, 0));
+    TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.copy_stream));
+    TSTWO_HIP(hipEventRecord(c.copy_done, c.copy_stream));
+    c.copy_pending = true;
+    return TSTWO_OK;
+}
+int tstwo_upload_fence(void) {
+    TSTWO_REQUIRE_READY();
+    Context &c = g_ctx;
+    if (c.copy_pending) TSTWO_HIP(hipStreamWaitEvent(c.stream, c.copy_done, 0));
+    return TSTWO_OK;
+}
+int tstwo_upload_wait(void) {
+    TSTWO_REQUIRE_READY();
+    Context &c = g_ctx;
+    if (c.copy_pending) TSTWO_HIP(hipStreamSynchronize(c.copy_stream));
     return TSTWO_OK;
 }
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes) {

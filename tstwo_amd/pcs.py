@@ -101,6 +101,32 @@ class CommitmentTreeProver:
         channel.mix_root(tree.root())
         return CommitmentTreeProver(list(polynomials), evaluations, tree)
 
+    @staticmethod
+    def new_many(polynomial_sets, log_blowup_factor: int, channel, twiddles: TwiddleTree) -> list:
+        """Several trees committed in ONE protocol phase (stwo's TreeVec: pcs/prover.ts:62-64 pushes a CommitmentTreeProver per
+        tree, each mixing its root, :227-228) — the same transcript as new() tree by tree, because nothing is drawn between the
+        commits of a phase: the roots are mixed in tree order once they exist.  Every polynomial of every tree goes through one
+        batched evaluation per size, and the trees through one tstwo_merkle_commit_many launch sequence (equally shaped trees
+        share their launches: BASELINE config 5's 8 trees of 32 columns)."""
+        polynomial_sets = [list(ps) for ps in polynomial_sets]
+        flat = [p for ps in polynomial_sets for p in ps]
+        by_size = {}
+        for i, p in enumerate(flat):
+            by_size.setdefault(p.logSize(), []).append(i)
+        evaluations = [None] * len(flat)
+        for log, idxs in by_size.items():
+            domain = CanonicCoset(log + log_blowup_factor).circleDomain()
+            for i, ev in zip(idxs, evaluate_polynomials([flat[i] for i in idxs], domain, twiddles)):
+                evaluations[i] = ev
+        per_tree, k = [], 0
+        for ps in polynomial_sets:
+            per_tree.append(evaluations[k:k + len(ps)])
+            k += len(ps)
+        trees = MerkleProver.commit_many([[ev.values for ev in evs] for evs in per_tree])
+        for t in trees:
+            channel.mix_root(t.root())
+        return [CommitmentTreeProver(ps, evs, t) for ps, evs, t in zip(polynomial_sets, per_tree, trees)]
+
     def decommit(self, queries: dict):
         return self.commitment.decommit(queries, [ev.values for ev in self.evaluations])
 
@@ -140,6 +166,11 @@ class CommitmentSchemeProver:
 
     def commit(self, polynomials, channel) -> None:
         self.trees.append(CommitmentTreeProver.new(polynomials, self.log_blowup_factor, channel, self.twiddles))
+
+    def commit_many(self, polynomial_sets, channel) -> None:
+        """The trees of one phase committed together (CommitmentTreeProver.new_many): same trees, roots and transcript as one
+        commit() per set."""
+        self.trees += CommitmentTreeProver.new_many(polynomial_sets, self.log_blowup_factor, channel, self.twiddles)
 
     def roots(self) -> list:
         return [t.commitment.root() for t in self.trees]
