@@ -284,6 +284,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 1-4 (the `configs` list of the JSON line)")
     ap.add_argument("--commit-per-tree", action="store_true", help="one tstwo_merkle_commit call per tree instead of one tstwo_merkle_commit_many per step (A/B)")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the from-host legs (registered-memory upload rate, pipelined upload + step)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the child rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--pmc-json", default=None, help="tools/pmc_summary.py output of an earlier --pmc run of THIS build, instead of the child passes")
     args = ap.parse_args()
@@ -366,7 +367,8 @@ def main():
         dev_cols.append(b)
     L.sync()
     t_up = time.perf_counter() - t_up                      # host -> device hand-over of the rank's columns (tstwo_col_upload from pageable numpy arrays): reported, never in `value`
-    if not want_cpu:
+    want_host = rank == 0 and world == 1 and not args.no_host_boundary       # the from-host legs below need the host copies too
+    if not want_cpu and not want_host:
         cols_host = None
     col_ptrs = L.ptr_array([b.ptr for b in dev_cols])
     tree_ptrs = [L.ptr_array([b.ptr for b in dev_cols[t * tree_cols:(t + 1) * tree_cols]]) for t in range(n_trees)]
@@ -467,6 +469,60 @@ def main():
     t_cfft = sum(e[0].elapsed_ms(e[1]) for e in evs)
     t_merkle = sum(e[1].elapsed_ms(e[2]) for e in evs)
 
+    # ---- the host boundary (never in `value`): what a caller pays who hands the trace over from HOST memory.
+    #  (i) page-locked source (the caller's arrays registered with tstwo_host_register) -> tstwo_upload_async: one DMA per column;
+    #  (ii) a whole step FROM HOST memory, pipelined: upload of tree k+1's columns on the copy stream under evaluate + commit of
+    #       tree k on the main stream (tstwo_upload_async / tstwo_upload_fence) — against max(upload, compute) of the same run.
+    host_legs = None
+    if want_host:
+        t0 = time.perf_counter()
+        for h in cols_host:
+            L.host_register(h)
+        t_reg = time.perf_counter() - t0
+        L.sync()
+        t0 = time.perf_counter()
+        for h, b in zip(cols_host, dev_cols):
+            b.upload_async(h)
+        L.upload_wait()
+        t_pin = time.perf_counter() - t0
+
+        def step_from_host():
+            for c in range(tree_cols):
+                dev_cols[c].upload_async(cols_host[c])
+            for t in range(n_trees):
+                L.upload_fence()                                         # tree t's columns have landed before its transform starts
+                for c in range((t + 1) * tree_cols, min((t + 2) * tree_cols, n_cols)):
+                    dev_cols[c].upload_async(cols_host[c])               # tree t + 1 travels under tree t's kernels
+                L.call("tstwo_cfft_evaluate", tree_ptrs[t], tree_cols, n, half_initial, C.c_void_p(tw.ptr), n - 1)
+                L.call("tstwo_merkle_commit", tree_ptrs[t], log_sizes, tree_cols, C.c_void_p(layers[t].ptr), None)
+            L.sync()
+        step_from_host()
+        roots_from_host = my_roots()
+        L.sync()
+        t0 = time.perf_counter()
+        step_from_host()
+        t_pipe = time.perf_counter() - t0
+        # the same per-tree step with the columns already resident: the compute side of the pipeline
+        for h, b in zip(cols_host, dev_cols):
+            b.upload_async(h)
+        L.sync()
+        t0 = time.perf_counter()
+        for t in range(n_trees):
+            L.call("tstwo_cfft_evaluate", tree_ptrs[t], tree_cols, n, half_initial, C.c_void_p(tw.ptr), n - 1)
+            L.call("tstwo_merkle_commit", tree_ptrs[t], log_sizes, tree_cols, C.c_void_p(layers[t].ptr), None)
+        L.sync()
+        t_comp = time.perf_counter() - t0
+        for h in cols_host:
+            L.host_unregister(h)
+        host_legs = {"register_seconds": t_reg, "h2d_seconds_registered": t_pin, "h2d_GBps_registered": 4.0 * N * n_cols / t_pin / 1e9,
+                     "pipelined_step_ms": t_pipe * 1e3, "upload_alone_ms": t_pin * 1e3, "compute_alone_ms": t_comp * 1e3,
+                     "pipelined_over_max": t_pipe / max(t_pin, t_comp), "roots_match_resident_step": roots_from_host == gpu_roots_first,
+                     "pcie_inclusive_elems_per_s_pipelined": n_cols * N / t_pipe,
+                     "how": "tstwo_host_register on the numpy columns; tstwo_upload_async per column on the copy stream; tree k+1's columns "
+                            "travel under evaluate + commit of tree k (tstwo_upload_fence in front of each tree)"}
+        if not host_legs["roots_match_resident_step"]:
+            raise SystemExit("bench.py: the step fed from host memory gave other Merkle roots than the resident step")
+
     if use_dist:
         # every rank's roots must have arrived in rank order: compare the RCCL result with a gloo all-gather of the same roots
         last = (step_no[0] - 1) & 1
@@ -553,9 +609,9 @@ def main():
                                   "frac_of_dual_issue_peak": valu_rate / VALU_PEAK_DUAL_MEASURED}},
             # What a caller pays who hands the trace over from host memory on every step (the design does not: columns stay
             # resident from evaluate to the folds).  Measured on this run's own upload of the rank's columns; never `value`.
-            "host_boundary": {"h2d_seconds": t_up, "h2d_bytes": 4.0 * N * n_cols, "h2d_GBps": 4.0 * N * n_cols / t_up / 1e9,
-                              "source": "pageable numpy arrays through tstwo_col_upload, one call per column",
-                              "pcie_inclusive_elems_per_s": n_cols * N / (t_up + elapsed / steps)},
+            "host_boundary": dict({"h2d_seconds": t_up, "h2d_bytes": 4.0 * N * n_cols, "h2d_GBps": 4.0 * N * n_cols / t_up / 1e9,
+                                   "source": "pageable numpy arrays through tstwo_upload, one call per column",
+                                   "pcie_inclusive_elems_per_s": n_cols * N / (t_up + elapsed / steps)}, **(host_legs or {})),
             "device": L.device_name(),
         }
         root_ok = None

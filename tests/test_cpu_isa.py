@@ -72,7 +72,7 @@ def _is_light(ins):
     # round 3: the 8-rows-per-lane field kernels on field8.cuh (quotients, QM31 batch inverse through the norms).  Their
     # priority-0 stretches also hold what cannot be phased — the one Fermat chain per 8 values and the tree products around it
     # (f8::inverse8), issued in program order at low priority on purpose — hence the lower share of light instructions there.
-    ("quotients", r"k_quotients8ILb1ELb0E", 80, 0.7), ("quotients", r"k_quotients8ILb1ELb1E", 80, 0.7), ("quotients", r"k_quotients8_pairE", 80, 0.65), ("field_ops", r"k_qm31_batch_inverse_normE", 60, 0.7),
+    ("quotients", r"k_quotients8ILb1ELb0E", 80, 0.7), ("quotients", r"k_quotients8ILb1ELb1E", 80, 0.7), ("quotients", r"k_quotients8_multiILi2ELb0E", 80, 0.65), ("field_ops", r"k_qm31_batch_inverse_normE", 60, 0.7),
 ])
 def test_hot_kernels_are_phased_and_use_global_memory_instructions(tu, pattern, min_phases, min_light_share, tmp_path):
     kernels = _disasm(tu, tmp_path)

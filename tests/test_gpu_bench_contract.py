@@ -34,7 +34,8 @@ def test_bench_line_contract_at_reduced_size():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and len(c["roots"]) == 2
     assert d["root_match"] is True and d["gpu_roots"] == c["roots"]    # the GPU's roots of the first step == the oracle's
-    assert d["host_boundary"]["h2d_GBps"] > 0
+    hb = d["host_boundary"]
+    assert hb["h2d_GBps"] > 0 and hb["h2d_GBps_registered"] > 0 and hb["roots_match_resident_step"] is True and hb["pipelined_step_ms"] > 0
 
 
 def test_bench_two_ranks_rehearsed_on_one_gpu():

@@ -1043,3 +1043,94 @@ def test_quotients_two_batches_over_one_column_list(log, n_cols, golden):
         exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (5, 6, 7, 8), batches)
         for k in range(4):
             assert (host(out[k], 1 << log) == exp[k]).all(), (log, n_cols, second[:3], k)
+
+
+@pytest.mark.parametrize("log,n_cols,k", [(10, 5, 3), (12, 32, 3), (9, 4, 4), (13, 9, 4), (11, 6, 5), (12, 3, 7), (5, 4, 3)])
+def test_quotients_k_batches_over_one_column_list(log, n_cols, k, golden):
+    """Every column opened at k points (k sample batches over the SAME column list): sweeps of 3 or 2 batches that load the column
+    words once per sweep and continue from the rows the previous sweep wrote (k_quotients8_multi<NB, ACCUM>), against the oracle's
+    per-row reference loop; and the same input with ONE batch's columns in another order, which must take the general kernel and
+    give the oracle's rows as well."""
+    px, py = golden["eval_at_point"][0]["point"]
+    pts = [(px, py)]
+    for _ in range(k - 1):                                   # further points on the QM31 circle: repeated doubling
+        x, y = pts[-1]
+        x2 = OL.orc_qm31_mul(orc.q(x), orc.q(x)).tup()
+        xy = OL.orc_qm31_mul(orc.q(x), orc.q(y)).tup()
+        P_ = 2147483647
+        pts.append((tuple((2 * a - (1 if i == 0 else 0)) % P_ for i, a in enumerate(x2)), tuple((2 * a) % P_ for a in xy)))
+    cols = [rand_column(9700 + 7 * log + c, 1 << log) for c in range(n_cols)]
+    vals = [tuple(int(x) for x in rand_column(9900 + 3 * log + j, 4)) for j in range(k * n_cols)]
+    d = [dev(c) for c in cols]
+    for permuted in (None, k - 1, 0):
+        batches = []
+        for b in range(k):
+            order = list(range(n_cols))[::-1] if permuted == b else list(range(n_cols))
+            batches.append((pts[b][0], pts[b][1], [(c, vals[b * n_cols + i]) for i, c in enumerate(order)]))
+        off, cidx, points, values = [0], [], [], []
+        for bx, by, cv in batches:
+            points += [*bx, *by]
+            for ci, v in cv:
+                cidx.append(ci)
+                values += list(v)
+            off.append(len(cidx))
+        out = [L.DeviceBuffer(max(4 << log, 16)) for _ in range(4)]
+        for o in out:
+            L.call("tstwo_zero", vp(o), max(4 << log, 16))
+        L.call("tstwo_quotients_accumulate_samples", half_odds(log - 1), log, ptrs(d), n_cols, k, L.u32x(off), L.u32x(cidx),
+               L.u32x(points), L.u32x(values), L.u32x((5, 6, 7, 8)), p4(out))
+        exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (5, 6, 7, 8), batches)
+        for c in range(4):
+            assert (host(out[c], 1 << log) == exp[c]).all(), (log, n_cols, k, permuted, c)
+
+
+def test_upload_async_from_registered_and_library_pinned_memory():
+    """tstwo_host_register / tstwo_host_alloc + tstwo_upload_async / _fence / _wait (the createBaseFieldColumn boundary,
+    backend/index.ts:20-31): copies issued on the copy stream land before main-stream work enqueued behind the fence, never
+    overtake main-stream work enqueued before them, and a pipelined upload-under-transform gives the oracle's evaluations."""
+    n = 16
+    N = 1 << n
+    tw = dev_empty(1 << (n - 1))
+    L.call("tstwo_twiddles_build", half_odds(n - 1), n - 1, vp(tw), vp(None))
+    otw = orc.precompute_twiddles(half_odds(n - 1), n - 1, inverse=False)[0]
+    cols = [rand_column(5600 + c, N) for c in range(6)]
+    # (a) registered caller memory, (b) library-pinned memory, (c) pageable memory: all three must arrive
+    reg = cols[0].copy()
+    L.host_register(reg)
+    pin = L.PinnedArray(N)
+    pin.array[:] = cols[1]
+    d = [dev_empty(N) for _ in range(3)]
+    d[0].upload_async(reg)
+    d[1].upload_async(pin.array)
+    d[2].upload_async(cols[2])
+    L.upload_fence()
+    L.call("tstwo_cfft_evaluate", ptrs(d), 3, n, half_odds(n - 1), vp(tw), n - 1)      # behind the fence: sees the uploaded words
+    L.upload_wait()
+    for k in range(3):
+        assert (host(d[k], N) == orc.cfft_evaluate(cols[k], n, half_odds(n - 1), otw, n - 1)).all()
+    # a copy does not overtake work enqueued before it: transform in place, THEN overwrite with fresh words
+    d2 = dev(cols[3])
+    L.call("tstwo_cfft_evaluate", ptrs([d2]), 1, n, half_odds(n - 1), vp(tw), n - 1)
+    pin.array[:] = cols[4]
+    d2.upload_async(pin.array)
+    L.sync()                                                                           # tstwo_sync also waits for unfenced copies
+    assert (host(d2, N) == cols[4]).all()
+    # pipeline: column k+1 travels while column k is transformed
+    pins = [L.PinnedArray(N) for _ in range(4)]
+    for k in range(4):
+        pins[k].array[:] = cols[k + 2]
+    dd = [dev_empty(N) for _ in range(4)]
+    dd[0].upload_async(pins[0].array)
+    for k in range(4):
+        L.upload_fence()
+        if k + 1 < 4:
+            dd[k + 1].upload_async(pins[k + 1].array)
+        L.call("tstwo_cfft_evaluate", ptrs([dd[k]]), 1, n, half_odds(n - 1), vp(tw), n - 1)
+    L.sync()
+    for k in range(4):
+        assert (host(dd[k], N) == orc.cfft_evaluate(cols[k + 2], n, half_odds(n - 1), otw, n - 1)).all()
+    L.host_unregister(reg)
+    for p_ in pins + [pin]:
+        p_.free()
+    with pytest.raises(L.TstwoError):
+        L.call("tstwo_host_register", vp(None), 16)

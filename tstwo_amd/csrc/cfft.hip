@@ -221,7 +221,9 @@ __device__ __forceinline__ int plan_stages(const PassParams &pp, int *g_out) {
 // in LDS and reused for every column; the next column's tile is prefetched into registers while
 // the current one is transformed, so HBM latency overlaps the butterflies inside the workgroup.
 template <bool INV, int THREADS>
-__global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 3)) k_cfft_pass(ColPtrs cols, u32 n_cols, PassParams pp) {
+// (512 lanes = the strided passes of the generic route, which only the experiments build's TSTWO_CFFT_GENERIC reaches: asked for 2
+// waves per SIMD it keeps its radix-32 stage in registers; at 4 it spilled 120-132 bytes per lane at 128 VGPRs)
+__global__ void __launch_bounds__(THREADS, (THREADS == 512 ? 2 : 3)) k_cfft_pass(ColPtrs cols, u32 n_cols, PassParams pp) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const u32 tile_words = 1u << pp.logt;
     u32 *twl = lds + ((tile_words + (tile_words >> 5) + 3u) & ~3u);     // twiddle heap behind the padded tile

@@ -33,14 +33,18 @@ struct Context {
     hipEvent_t up_done[16] = {};      // recorded behind the copy that last used the slot
     bool up_busy[16] = {};
     int up_next = 0;
-    hipStream_t copy_stream = nullptr;   // tstwo_upload_async: host -> device copies beside the kernels of `stream`, fenced by the two events below
-    hipEvent_t copy_after = nullptr;     // recorded on `stream`, waited for by copy_stream: a copy never overtakes work enqueued before it
-    hipEvent_t copy_done = nullptr;      // recorded on copy_stream behind the last copy: tstwo_upload_fence makes `stream` wait for it
-    bool copy_pending = false;
+    // tstwo_upload_async: host -> device copies beside the kernels of `stream`, on kCopyStreams copy streams taken in turn (one
+    // stream = one DMA engine at a time; two keep the link busy across the gap between consecutive copies)
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
+    hipEvent_t copy_after = nullptr;     // recorded on `stream`, waited for by the copy stream: a copy never overtakes work enqueued before it
+    hipEvent_t copy_done[2] = {nullptr, nullptr};   // recorded behind the last copy of each stream: tstwo_upload_fence makes `stream` wait for them
+    bool copy_pending[2] = {false, false};
+    int copy_next = 0;
 };
 constexpr size_t kPinnedBytes = 64 * 1024;
 constexpr size_t kResultBytes = 256 * 1024;
 constexpr int kUpSlots = 16;
+constexpr int kCopyStreams = 2;
 constexpr size_t kUpSlotBytes = 16 * 1024;
 
 // Experiment and A/B-timing switches.  The SHIPPED library never takes them from its caller's environment:
@@ -73,6 +77,7 @@ struct Knobs {
     // field_ops.hip / quotients.hip
     int qinv_k = 0;                    // TSTWO_QINV_K
     bool qinv_montgomery = false, quot_no_lazy = false, quot_no_pair = false;
+    bool quot_no_triple = false;       // TSTWO_QUOT_NO_TRIPLE: k batches over one column list as sweeps of 2 (+ 1) instead of 3 / 2 (A/B)
     // context.hip
     bool device_flag = false;          // TSTWO_DEVICE_FLAG: zero-inverse flag / result page in device memory
 };

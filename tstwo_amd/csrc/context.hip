@@ -43,6 +43,7 @@ static Knobs read_knobs() {
     k.fold_cap = num("TSTWO_FOLD_CAP", 64); k.fold1 = on("TSTWO_FOLD1");
     k.qinv_k = num("TSTWO_QINV_K", 0); k.qinv_montgomery = on("TSTWO_QINV_MONTGOMERY");
     k.quot_no_lazy = on("TSTWO_QUOT_NO_LAZY"); k.quot_no_pair = on("TSTWO_QUOT_NO_PAIR");
+    k.quot_no_triple = on("TSTWO_QUOT_NO_TRIPLE");
     k.device_flag = on("TSTWO_DEVICE_FLAG");
     return k;
 }
@@ -394,11 +395,13 @@ int tstwo_shutdown(void) {
     if (c.coltab) (void)hipFree(c.coltab);
     coltab_cache_reset();
     if (c.scratch) (void)hipFree(c.scratch);
-    if (c.copy_stream) {
-        (void)hipStreamSynchronize(c.copy_stream);
+    if (c.copy_stream[0]) {
+        for (int i = 0; i < kCopyStreams; i++) {
+            (void)hipStreamSynchronize(c.copy_stream[i]);
+            (void)hipEventDestroy(c.copy_done[i]);
+            (void)hipStreamDestroy(c.copy_stream[i]);
+        }
         (void)hipEventDestroy(c.copy_after);
-        (void)hipEventDestroy(c.copy_done);
-        (void)hipStreamDestroy(c.copy_stream);
     }
     if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
     c = Context();
@@ -459,10 +462,8 @@ int tstwo_graph_destroy(void *graph_exec) {
 int tstwo_sync(void) {
     TSTWO_REQUIRE_READY();
     TSTWO_HIP(hipStreamSynchronize(g_ctx.stream));
-    if (g_ctx.copy_pending) {            // copies of tstwo_upload_async that nothing fenced: "everything the library was asked to do is done"
-        TSTWO_HIP(hipStreamSynchronize(g_ctx.copy_stream));
-        g_ctx.copy_pending = false;
-    }
+    for (int i = 0; i < kCopyStreams; i++)          // copies of tstwo_upload_async that nothing fenced: "everything the library was asked to do is done"
+        if (g_ctx.copy_pending[i]) { TSTWO_HIP(hipStreamSynchronize(g_ctx.copy_stream[i])); g_ctx.copy_pending[i] = false; }
     return TSTWO_OK;
 }
 
@@ -606,28 +607,34 @@ int tstwo_upload_async(void *dev_dst, const void *host_src, size_t bytes) {
     TSTWO_REQUIRE_PTRS(dev_dst, host_src);
     Context &c = g_ctx;
     if (int rc = refuse_if_capturing(c.stream)) return rc;
-    if (!c.copy_stream) {
-        TSTWO_HIP(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    if (!c.copy_stream[0]) {
+        for (int i = 0; i < kCopyStreams; i++) {
+            TSTWO_HIP(hipStreamCreateWithFlags(&c.copy_stream[i], hipStreamNonBlocking));
+            TSTWO_HIP(hipEventCreateWithFlags(&c.copy_done[i], hipEventDisableTiming));
+        }
         TSTWO_HIP(hipEventCreateWithFlags(&c.copy_after, hipEventDisableTiming));
-        TSTWO_HIP(hipEventCreateWithFlags(&c.copy_done, hipEventDisableTiming));
     }
+    const int i = c.copy_next;
+    c.copy_next = (i + 1) % kCopyStreams;
     TSTWO_HIP(hipEventRecord(c.copy_after, c.stream));
-    TSTWO_HIP(hipStreamWaitEvent(c.copy_stream, c.copy_after, 0));
-    TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.copy_stream));
-    TSTWO_HIP(hipEventRecord(c.copy_done, c.copy_stream));
-    c.copy_pending = true;
+    TSTWO_HIP(hipStreamWaitEvent(c.copy_stream[i], c.copy_after, 0));
+    TSTWO_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c.copy_stream[i]));
+    TSTWO_HIP(hipEventRecord(c.copy_done[i], c.copy_stream[i]));
+    c.copy_pending[i] = true;
     return TSTWO_OK;
 }
 int tstwo_upload_fence(void) {
     TSTWO_REQUIRE_READY();
     Context &c = g_ctx;
-    if (c.copy_pending) TSTWO_HIP(hipStreamWaitEvent(c.stream, c.copy_done, 0));
+    for (int i = 0; i < kCopyStreams; i++)
+        if (c.copy_pending[i]) TSTWO_HIP(hipStreamWaitEvent(c.stream, c.copy_done[i], 0));
     return TSTWO_OK;
 }
 int tstwo_upload_wait(void) {
     TSTWO_REQUIRE_READY();
     Context &c = g_ctx;
-    if (c.copy_pending) TSTWO_HIP(hipStreamSynchronize(c.copy_stream));
+    for (int i = 0; i < kCopyStreams; i++)
+        if (c.copy_pending[i]) { TSTWO_HIP(hipStreamSynchronize(c.copy_stream[i])); c.copy_pending[i] = false; }
     return TSTWO_OK;
 }
 int tstwo_download(void *host_dst, const void *dev_src, size_t bytes) {

@@ -265,14 +265,17 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
     }
 }
 
-// Two sample batches over the SAME column list (every column opened at two points, z and z·g: the common AIR shape).  The two
-// batches' numerators are sums over the same column words with different coefficients, so the words are loaded ONCE and feed both
-// (k_quotients8 reads every column again per batch: 32 columns x 2^22 took 0.235 ms for two batches against 0.149 for one, the
-// difference being the second trip of 512 MiB through memory).  Same arithmetic as k_quotients8<., LAZY> otherwise; the result
-// (0 * coeff_0 + term_0) * coeff_1 + term_1 of a half goes straight to memory.
-__global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
-                                                        const BatchConst *__restrict__ batches, const Entry *__restrict__ entries, Soa4 out,
-                                                        const cpoint *__restrict__ gen_pow2, cpoint qb, u32 bsel, u32 *flag) {
+// NB (2 or 3) sample batches over the SAME column list (every column opened at two points, z and z·g: the common AIR shape; three
+// for columns that also look one row back).  The batches' numerators are sums over the same column words with different
+// coefficients, so the words are loaded ONCE and feed all of them (k_quotients8 reads every column again per batch: 32 columns x
+// 2^22 took 0.235 ms for two batches against 0.149 for one, the difference being the second trip of 512 MiB through memory).
+// Same arithmetic as k_quotients8<., LAZY> otherwise; the result (..(acc * coeff_0 + term_0) * coeff_1 + term_1 ..) of a half goes
+// straight to memory, with acc = 0, or — ACCUM — the rows a previous launch left in `out`: a column list opened at k points is
+// ceil(k / 3) sweeps over the columns (k = 4: two sweeps of two) instead of k.  NB = 3 holds 96 VGPRs of 64-bit sums: 3 waves per SIMD.
+template <int NB, bool ACCUM>
+__global__ void __launch_bounds__(256) k_quotients8_multi(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
+                                                         const BatchConst *__restrict__ batches, const Entry *__restrict__ entries, Soa4 out,
+                                                         const cpoint *__restrict__ gen_pow2, cpoint qb, u32 bsel, u32 *flag) {
     const size_t n_threads = (size_t)1 << (log_size - 3);
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_threads) return;
@@ -284,9 +287,9 @@ __global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 l
     u32 xy[8] = {p0.x, p1.x, p0.y, p1.y, p0.x, p1.x, p0.y, p1.y};
     u32 yy[8] = {p0.y, p0.y, p0.y, p0.y, p1.y, p1.y, p1.y, p1.y};
     bool zero = false;
-    u32 ir[2][8], ii[2][8], ay[2][8];
+    u32 ir[NB][8], ii[NB][8], ay[NB][8];
 #pragma unroll
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < NB; b++) {
         const BatchConst bc = batches[b];
         const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));
         u32 m8[8] = {M31_P - bc.piy.a, M31_P - bc.piy.a, bc.pix.a, bc.pix.a, M31_P - bc.piy.b, M31_P - bc.piy.b, bc.pix.b, bc.pix.b}, pr[8];
@@ -318,32 +321,41 @@ __global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 l
         u32 a8[8] = {bc.A.a, bc.A.b, bc.A.c, bc.A.d, bc.A.a, bc.A.b, bc.A.c, bc.A.d};
         f8::mul(ay[b], a8, yy);
     }
-    const u32 begin0 = batches[0].begin, begin1 = batches[1].begin, n_entries = batches[0].end - batches[0].begin;
+    u32 begin[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) begin[b] = batches[b].begin;
+    const u32 n_entries = batches[0].end - batches[0].begin;
 #pragma unroll 1          // (rolled on purpose: one copy of the body; ay / ir / ii are then indexed by `half` at run time — eight LDS accesses per lane)
     for (int half = 0; half < 2; half++) {
-        u64 accq[2][2][8];
+        u64 accq[NB][2][8];
 #pragma unroll
-        for (int s = 0; s < 8; s++) accq[0][0][s] = accq[0][1][s] = accq[1][0][s] = accq[1][1][s] = 0ull;
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int s = 0; s < 8; s++) accq[b][0][s] = accq[b][1][s] = 0ull;
         u32 two = 2u;
         asm volatile("" : "+v"(two));
         for (u32 j = 0; j < n_entries; j += 4) {
             const u32 cnt = min(4u, n_entries - j);                    // wave-uniform
-            u32 cw[2][4][4], f[4][4];
+            u32 cw[NB][4][4], f[4][4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const u32 je = j + (e < (int)cnt ? e : 0);
-                const Entry en0 = entries[begin0 + je], en1 = entries[begin1 + je];          // same column, two coefficient sets
-                const uint4 fv = gload4(cols[en0.col], half ? rowB : rowA);
-                f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
                 const bool on = e < (int)cnt;
-                cw[0][e][0] = on ? en0.c.a : 0u; cw[0][e][1] = on ? en0.c.b : 0u; cw[0][e][2] = on ? en0.c.c : 0u; cw[0][e][3] = on ? en0.c.d : 0u;
-                cw[1][e][0] = on ? en1.c.a : 0u; cw[1][e][1] = on ? en1.c.b : 0u; cw[1][e][2] = on ? en1.c.c : 0u; cw[1][e][3] = on ? en1.c.d : 0u;
+#pragma unroll
+                for (int b = 0; b < NB; b++) {                               // same column, NB coefficient sets
+                    const Entry en = entries[begin[b] + je];
+                    if (b == 0) {
+                        const uint4 fv = gload4(cols[en.col], half ? rowB : rowA);
+                        f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
+                    }
+                    cw[b][e][0] = on ? en.c.a : 0u; cw[b][e][1] = on ? en.c.b : 0u; cw[b][e][2] = on ? en.c.c : 0u; cw[b][e][3] = on ? en.c.d : 0u;
+                }
             }
             u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
                             {f[2][0], f[2][1], f[2][2], f[2][3], f[3][0], f[3][1], f[3][2], f[3][3]}};
             f8::boundary<kPrioHeavy>(fp[0], fp[1]);
 #pragma unroll
-            for (int b = 0; b < 2; b++)
+            for (int b = 0; b < NB; b++)
 #pragma unroll
                 for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -354,12 +366,13 @@ __global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 l
                         for (int e = 0; e < 4; e++) a += (u64)cw[b][e][k] * (u64)fp[e >> 1][4 * (e & 1) + r];
                         accq[b][h][s] = a;
                     }
-            f8::pin(accq[0][0]); f8::pin(accq[0][1]); f8::pin(accq[1][0]); f8::pin(accq[1][1]);
+#pragma unroll
+            for (int b = 0; b < NB; b++) { f8::pin(accq[b][0]); f8::pin(accq[b][1]); }
             f8::done();
         }
-        u32 term[2][2][8];
+        u32 term[NB][2][8];
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < NB; b++) {
             const BatchConst bc = batches[b];
             u32 num[2][8];
             f8::reduce(num[0], accq[b][0]);
@@ -392,13 +405,28 @@ __global__ void __launch_bounds__(256) k_quotients8_pair(u32 half_initial, u32 l
             }
         }
         f8::done();
-        const qm31 coeff1 = batches[1].coeff;
         u32 o[4][4];
+        if constexpr (ACCUM) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const qm31 m = qm31_mul({term[0][0][r], term[0][0][4 + r], term[0][1][r], term[0][1][4 + r]}, coeff1);
-            o[0][r] = m31_add(m.a, term[1][0][r]); o[1][r] = m31_add(m.b, term[1][0][4 + r]);
-            o[2][r] = m31_add(m.c, term[1][1][r]); o[3][r] = m31_add(m.d, term[1][1][4 + r]);
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = gload4(out.p[k], half ? rowB : rowA);
+                o[k][0] = v.x; o[k][1] = v.y; o[k][2] = v.z; o[k][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            if (b == 0 && !ACCUM) {                  // the accumulator is zero before the first batch
+#pragma unroll
+                for (int r = 0; r < 4; r++) { o[0][r] = term[0][0][r]; o[1][r] = term[0][0][4 + r]; o[2][r] = term[0][1][r]; o[3][r] = term[0][1][4 + r]; }
+                continue;
+            }
+            const qm31 cf = batches[b].coeff;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const qm31 m = qm31_mul({o[0][r], o[1][r], o[2][r], o[3][r]}, cf);
+                o[0][r] = m31_add(m.a, term[b][0][r]); o[1][r] = m31_add(m.b, term[b][0][4 + r]);
+                o[2][r] = m31_add(m.c, term[b][1][r]); o[3][r] = m31_add(m.d, term[b][1][4 + r]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) gstore4(out.p[k], half ? rowB : rowA, make_uint4(o[k][0], o[k][1], o[k][2], o[k][3]));
@@ -514,12 +542,30 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         const dim3 grid(ceil_div(n_threads, 256));
         // two batches over one column list (same columns in the same order): the column words are loaded once for both
         const bool no_pair = knobs().quot_no_pair;          // (A/B timing)
-        bool pair = n_batches == 2 && !no_pair && batch_off[1] - batch_off[0] == batch_off[2] - batch_off[1] && batch_off[1] > batch_off[0];
-        for (size_t j = batch_off[0]; pair && j < batch_off[1]; j++) pair = col_idx[j] == col_idx[j - batch_off[0] + batch_off[1]];
+        // k >= 2 batches over ONE column list (the same columns in the same order in every batch): sweeps of 3 or 2 batches, the later
+        // sweeps continuing from the rows the earlier ones wrote (k = 2: 2; 3: 3; 4: 2 + 2; 5: 3 + 2; ...)
+        bool pair = n_batches >= 2 && !no_pair && batch_off[1] > batch_off[0];
+        const u32 per = pair ? batch_off[1] - batch_off[0] : 0;
+        for (size_t bb = 1; pair && bb < n_batches; bb++) {
+            pair = batch_off[bb + 1] - batch_off[bb] == per;
+            for (size_t j = 0; pair && j < per; j++) pair = col_idx[batch_off[0] + j] == col_idx[batch_off[bb] + j];
+        }
         if (pair) {
-            hipLaunchKernelGGL(k_quotients8_pair, grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, d_cols, d_b, d_e, o4, c.gen_win,
-                               qb, bsel, c.flag);
-            TSTWO_LAUNCH_CHECK();
+            size_t done = 0;
+            while (done < n_batches) {
+                const size_t left = n_batches - done;
+                const int nb = knobs().quot_no_triple ? (left >= 2 ? 2 : 1) : ((left == 2 || left == 4) ? 2 : 3);
+#define TSTWO_QMULTI(NBV, ACC) hipLaunchKernelGGL((k_quotients8_multi<NBV, ACC>), grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, \
+                                                  d_cols, d_b + done, d_e, o4, c.gen_win, qb, bsel, c.flag)
+                if (nb == 1) TSTWO_QMULTI(1, true);
+                else if (nb == 2 && done == 0) TSTWO_QMULTI(2, false);
+                else if (nb == 2) TSTWO_QMULTI(2, true);
+                else if (done == 0) TSTWO_QMULTI(3, false);
+                else TSTWO_QMULTI(3, true);
+#undef TSTWO_QMULTI
+                TSTWO_LAUNCH_CHECK();
+                done += (size_t)nb;
+            }
             return TSTWO_OK;
         }
 #define TSTWO_QLAUNCH(S, Z) hipLaunchKernelGGL((k_quotients8<S, Z>), grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, d_cols, d_b, \
