@@ -3,7 +3,7 @@
 # Output goes to gpurun_out/$TAG/ (scratch); tools/collect_profiles.sh copies the summaries into profiles/.
 # Every profiled command sits behind `timeout -k`, and a progress line is printed after each stage.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -41,9 +41,15 @@ echo "callers done"
 $T 300 python3 tools/bench_fri_sizes.py > $O/fri_sizes.log 2>&1
 echo "fri sizes done"
 # the N = 2 control flow of the strong-scaling bench on the one GPU (roots through the host) and the RCCL path at world size 1
-TSTWO_BENCH_COLLECTIVE=gloo $T 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 --no-configs > $O/bench_gloo2_rehearsal.json 2> $O/bench_gloo2.err
+# (round 4: bench.py --gpus 2 starts its own two ranks; both share the one GPU here, so the roots travel through the host: gloo)
+TSTWO_BENCH_COLLECTIVE=gloo $T 400 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-configs > $O/bench_gloo2_rehearsal.json 2> $O/bench_gloo2.err
 TSTWO_FORCE_DIST=1 $T 300 python3 bench.py --steps 5 --warmup 2 --no-configs --no-cpu --no-pmc > $O/bench_rccl_world1.json 2> $O/bench_rccl1.err
 echo "rehearsals done"
+# round 4: size sweep of the transform, k sample batches over one column list, host -> device rates
+$T 600 bash tools/cfft_sweep.sh > $O/cfft_sweep.txt 2>&1
+($T 200 python3 tools/quot_k_time.py --kmax 5; $T 200 python3 tools/quot_k_time.py --kmax 4 --cols 256 --log 20) > $O/quot_k.txt 2>&1
+$T 200 python3 tools/h2d_rate.py > $O/h2d_rate.txt 2>&1
+echo "sweeps done"
 rm -rf $O/stats $O/stats_configs $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2      # raw traces are large; summaries are what is kept
 ls -la $O
 sha256sum $R/tstwo_amd/libtstwo_hip.so | cut -c1-16 > $O/lib_sha16.txt

@@ -498,10 +498,10 @@ int launch_fast_kernel(KernelT kernel, int threads, size_t lds_bytes, size_t til
     return TSTWO_OK;
 }
 
-template <bool INV, int K, int LOGTA = 14>
+template <bool INV, int K, int LOGTA = 14, int V = (LOGTA == 15 ? 2 : 1)>
 int launch_a(u32 *const *cols, size_t n_cols, u32 n, u32 lo, const u32 *tw_end, u32 scale) {
     const size_t tiles = (size_t)1 << (n - LOGTA);
-    return launch_fast_kernel(fast::k_cfft_a<INV, K, 0, LOGTA>, LOGTA == 15 ? 1024 : 1 << (LOGTA - 4),
+    return launch_fast_kernel(fast::k_cfft_a<INV, K, 0, LOGTA, V>, (1 << (LOGTA - 4)) / V,
                               ((size_t)(1 << LOGTA) + (1 << (LOGTA - 5)) + ((size_t)1 << K)) * sizeof(u32), tiles, cols, n_cols, n, lo, tw_end, scale);
 }
 
@@ -588,6 +588,10 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         }
     }
     if (logta != 14) return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
+#ifdef TSTWO_EXPERIMENTS      // TSTWO_CFFT_AV=2: the 2^14 tile on 512 lanes x 32 words, two workgroups per CU (measured slower: 3.86 against 3.75 ms)
+    if (knobs().cfft_av == 2 && (ps.k == 8 || ps.k == 9))
+        return ps.k == 9 ? launch_a<INV, 9, 14, 2>(cols, n_cols, n, ps.lo, tw_end, scale) : launch_a<INV, 8, 14, 2>(cols, n_cols, n, ps.lo, tw_end, scale);
+#endif
     switch (ps.k) {
         case 1: return launch_a<INV, 1>(cols, n_cols, n, ps.lo, tw_end, scale);
         case 2: return launch_a<INV, 2>(cols, n_cols, n, ps.lo, tw_end, scale);

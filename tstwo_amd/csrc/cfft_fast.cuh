@@ -345,21 +345,23 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), TSTWO_B_WAVES) k_cfft_b(ColPt
 // after the other inside every stage — the same stage code, twice the work between two barriers, twice the bytes in flight per
 // CU — so that a 10-layer pass keeps 128-byte rows (n = 24 = 14 + 10: two passes over HBM instead of three) and a 9-layer pass
 // has 256-byte rows.
+// V = 2 at LOGT = 14 (512 lanes x 32 words, 66 KiB: TWO workgroups per CU, i.e. two independent barrier domains where the 2^15
+// tile has one) is instantiated for A/B timing (experiments build: TSTWO_CFFT_AV=2).
 #ifdef TSTWO_A_WAVES          // experiments: minimum waves per SIMD asked of the strided pass (8 = two 1024-lane workgroups per CU)
-#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__((LOGT) == 15 ? 1024 : 1 << ((LOGT) - 4), TSTWO_A_WAVES)
+#define TSTWO_A_BOUNDS(LOGT, V) __launch_bounds__((1 << ((LOGT) - 4)) / (V), TSTWO_A_WAVES)
 #else
-#define TSTWO_A_BOUNDS(LOGT) __launch_bounds__((LOGT) == 15 ? 1024 : 1 << ((LOGT) - 4))
+#define TSTWO_A_BOUNDS(LOGT, V) __launch_bounds__((1 << ((LOGT) - 4)) / (V))
 #endif
-template <bool INV, int K, int EXT = 0, int LOGT = 14>
-__global__ void TSTWO_A_BOUNDS(LOGT) k_cfft_a(ColPtrs cols, typename SrcTable<EXT>::type src, u32 n_cols, u32 total_items, u32 n,
-                                                u32 lo, const u32 *__restrict__ tw_end, u32 scale) {
+template <bool INV, int K, int EXT = 0, int LOGT = 14, int V = (LOGT == 15 ? 2 : 1)>
+__global__ void TSTWO_A_BOUNDS(LOGT, V) k_cfft_a(ColPtrs cols, typename SrcTable<EXT>::type src, u32 n_cols, u32 total_items, u32 n,
+                                                   u32 lo, const u32 *__restrict__ tw_end, u32 scale) {
     static_assert(EXT == 0 || (!INV && K >= 2 && EXT <= 2), "fused extension: forward pass with two register layers");
     static_assert(LOGT >= 12 && LOGT <= 15 && LOGT - K >= 4, "strided tile: rows of at least 16 words");
-    constexpr int V = LOGT == 15 ? 2 : 1;      // virtual lanes (16 words each) per lane
+    static_assert((V == 1 || V == 2) && (1 << (LOGT - 4)) / V <= 1024, "virtual lanes (16 words each) per lane");
 #ifdef TSTWO_A_SB
     constexpr bool SB = true;
 #else
-    constexpr bool SB = LOGT == 15;            // scalar-base addressing (below)
+    constexpr bool SB = V == 2;                // scalar-base addressing (below)
 #endif
     constexpr int VT = 1 << (LOGT - 4);        // virtual lanes per tile
     constexpr int THREADS = VT / V, C = LOGT - K;

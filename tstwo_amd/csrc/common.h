@@ -59,6 +59,7 @@ struct Knobs {
     int cfft_lds_pad = 0;              // TSTWO_CFFT_LDS_PAD: extra dynamic LDS per workgroup (lowers residency)
     int cfft_kb = 0, cfft_ka = 0;      // TSTWO_CFFT_KB (11-15) / TSTWO_CFFT_KA (1-10): bottom tile / strided layer limit (0 = planner)
     int cfft_logta = 0;                // TSTWO_CFFT_LOGTA (12-15): strided tile (0 = planner)
+    int cfft_av = 0;                   // TSTWO_CFFT_AV=2: 2^14-word strided tiles on 512 lanes x 32 words (two workgroups per CU)
     int cfft_generic = 0;              // TSTWO_CFFT_GENERIC: bit 0 / 1 generic kernel for bottom / strided passes, bit 2 SKIP the bottom pass
     int cfft_group = 0;                // TSTWO_CFFT_GROUP: Infinity-Cache column grouping
     bool cfft_trace = false, cfft_sync = false;             // TSTWO_CFFT_TRACE / TSTWO_CFFT_SYNC
@@ -77,6 +78,7 @@ struct Knobs {
     // field_ops.hip / quotients.hip
     int qinv_k = 0;                    // TSTWO_QINV_K
     bool qinv_montgomery = false, quot_no_lazy = false, quot_no_pair = false;
+    bool quot_no_rowpair = false;      // TSTWO_QUOT_NO_ROWPAIR: 3+ batches over one column list through k_quotients8_multi sweeps instead of k_quotients_rp (A/B)
     bool quot_no_triple = false;       // TSTWO_QUOT_NO_TRIPLE: k batches over one column list as sweeps of 2 (+ 1) instead of 3 / 2 (A/B)
     // context.hip
     bool device_flag = false;          // TSTWO_DEVICE_FLAG: zero-inverse flag / result page in device memory
@@ -173,6 +175,11 @@ __device__ __forceinline__ void gstore4(u32 *base, u32 word_off, uint4 x) {
     u32x4_t v;
     v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
     *(TSTWO_GLOBAL u32x4_t *)((TSTWO_GLOBAL char *)base + (word_off << 2)) = v;
+}
+__device__ __forceinline__ void gstore2(u32 *base, u32 word_off, uint2 x) {
+    u32x2_t v;
+    v.x = x.x; v.y = x.y;
+    *(TSTWO_GLOBAL u32x2_t *)((TSTWO_GLOBAL char *)base + (word_off << 2)) = v;
 }
 __device__ __forceinline__ void gstore1(u32 *base, u32 word_off, u32 x) { *(TSTWO_GLOBAL u32 *)((TSTWO_GLOBAL char *)base + (word_off << 2)) = x; }
 // Column pointer i.  Written as a branch, not as `c.ext ? c.ext[i] : c.p[i]`: the compiler merged that into ONE load through a

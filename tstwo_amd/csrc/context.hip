@@ -28,6 +28,7 @@ static Knobs read_knobs() {
     k.cfft_kb = num("TSTWO_CFFT_KB", 0); if (k.cfft_kb < 11 || k.cfft_kb > 15) k.cfft_kb = 0;
     k.cfft_ka = num("TSTWO_CFFT_KA", 0); if (k.cfft_ka < 1 || k.cfft_ka > 10) k.cfft_ka = 0;
     k.cfft_logta = num("TSTWO_CFFT_LOGTA", 0); if (k.cfft_logta < 12 || k.cfft_logta > 15) k.cfft_logta = 0;
+    k.cfft_av = num("TSTWO_CFFT_AV", 0);
     k.cfft_generic = num("TSTWO_CFFT_GENERIC", 0);
     k.cfft_group = num("TSTWO_CFFT_GROUP", 0);
     k.cfft_trace = on("TSTWO_CFFT_TRACE"); k.cfft_sync = on("TSTWO_CFFT_SYNC");
@@ -44,6 +45,7 @@ static Knobs read_knobs() {
     k.qinv_k = num("TSTWO_QINV_K", 0); k.qinv_montgomery = on("TSTWO_QINV_MONTGOMERY");
     k.quot_no_lazy = on("TSTWO_QUOT_NO_LAZY"); k.quot_no_pair = on("TSTWO_QUOT_NO_PAIR");
     k.quot_no_triple = on("TSTWO_QUOT_NO_TRIPLE");
+    k.quot_no_rowpair = on("TSTWO_QUOT_NO_ROWPAIR");
     k.device_flag = on("TSTWO_DEVICE_FLAG");
     return k;
 }

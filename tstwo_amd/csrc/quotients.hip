@@ -273,8 +273,8 @@ __global__ void __launch_bounds__(256) k_quotients8(u32 half_initial, u32 log_si
 // straight to memory, with acc = 0, or — ACCUM — the rows a previous launch left in `out`: a column list opened at k points is
 // ceil(k / 3) sweeps over the columns (k = 4: two sweeps of two) instead of k.  NB = 3 holds 96 VGPRs of 64-bit sums: 3 waves per SIMD.
 template <int NB, bool ACCUM>
-__global__ void __launch_bounds__(256) k_quotients8_multi(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
-                                                         const BatchConst *__restrict__ batches, const Entry *__restrict__ entries, Soa4 out,
+__global__ void __launch_bounds__(256) k_quotients8_multi(u32 half_initial, u32 log_size, const u32 *const *__restrict__ lp,
+                                                         const BatchConst *__restrict__ batches, const qm31 *__restrict__ lc, u32 n_entries, Soa4 out,
                                                          const cpoint *__restrict__ gen_pow2, cpoint qb, u32 bsel, u32 *flag) {
     const size_t n_threads = (size_t)1 << (log_size - 3);
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,10 +321,9 @@ __global__ void __launch_bounds__(256) k_quotients8_multi(u32 half_initial, u32 
         u32 a8[8] = {bc.A.a, bc.A.b, bc.A.c, bc.A.d, bc.A.a, bc.A.b, bc.A.c, bc.A.d};
         f8::mul(ay[b], a8, yy);
     }
-    u32 begin[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++) begin[b] = batches[b].begin;
-    const u32 n_entries = batches[0].end - batches[0].begin;
+    // (the shared column list as two compact tables: lp[j] = column pointer of position j, lc[b * n_entries + j] = batch b's
+    // coefficient there — 8 + 16 NB bytes per position instead of NB 32-byte Entry records and a dependent pointer load: a
+    // 256-column list of two batches is 10 KiB and stays in the 16 KiB scalar cache, where 18 KiB of records did not)
 #pragma unroll 1          // (rolled on purpose: one copy of the body; ay / ir / ii are then indexed by `half` at run time — eight LDS accesses per lane)
     for (int half = 0; half < 2; half++) {
         u64 accq[NB][2][8];
@@ -341,14 +340,14 @@ __global__ void __launch_bounds__(256) k_quotients8_multi(u32 half_initial, u32 
             for (int e = 0; e < 4; e++) {
                 const u32 je = j + (e < (int)cnt ? e : 0);
                 const bool on = e < (int)cnt;
+                {
+                    const uint4 fv = gload4(lp[je], half ? rowB : rowA);
+                    f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
+                }
 #pragma unroll
                 for (int b = 0; b < NB; b++) {                               // same column, NB coefficient sets
-                    const Entry en = entries[begin[b] + je];
-                    if (b == 0) {
-                        const uint4 fv = gload4(cols[en.col], half ? rowB : rowA);
-                        f[e][0] = fv.x; f[e][1] = fv.y; f[e][2] = fv.z; f[e][3] = fv.w;
-                    }
-                    cw[b][e][0] = on ? en.c.a : 0u; cw[b][e][1] = on ? en.c.b : 0u; cw[b][e][2] = on ? en.c.c : 0u; cw[b][e][3] = on ? en.c.d : 0u;
+                    const qm31 cq = lc[(u32)b * n_entries + je];
+                    cw[b][e][0] = on ? cq.a : 0u; cw[b][e][1] = on ? cq.b : 0u; cw[b][e][2] = on ? cq.c : 0u; cw[b][e][3] = on ? cq.d : 0u;
                 }
             }
             u32 fp[2][8] = {{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]},
@@ -434,6 +433,197 @@ __global__ void __launch_bounds__(256) k_quotients8_multi(u32 half_initial, u32 
     if (zero) raise_flag(flag);
 }
 
+// NB = 3 or 4 sample batches over ONE column list in ONE sweep (round 4).  k_quotients8_multi keeps a batch's numerator as 16 64-bit
+// sums (4 coordinates x 4 rows): three batches are 96 VGPRs of accumulators, 171 registers and 2 waves per SIMD in all.  Here a
+// lane's 8 rows are FOUR PAIRS of rows (r, r + 1) = (p, conj p), 128 rows apart, taken one after the other: a pair's numerators are
+// 8 sums per batch (4 coordinates x 2 rows), so four batches fit the registers the pair kernel uses for two.  A wave's 8-byte
+// accesses cover 512 consecutive bytes — whole lines — and its four sub-blocks are 512 consecutive rows in all.  What used to be
+// one Fermat chain per batch over a lane's 8 rows (inverse8) is one chain per PAIR over the pair's 2 NB denominators; the points of
+// the pairs are p0, p0 + Q7, p0 + Q8, p0 + Q7 + Q8 (row bits 7 and 8 <-> 2^24 and 2^23 generator steps).  Same arithmetic per row
+// as k_quotients8<., LAZY>; ACCUM continues from the rows already in `out`.  Needs log_size >= 9.
+template <int NB, bool ACCUM>
+__global__ void __launch_bounds__(256) k_quotients_rp(u32 half_initial, u32 log_size, const u32 *const *__restrict__ lp,
+                                                     const BatchConst *__restrict__ batches, const qm31 *__restrict__ lc, u32 n_entries, Soa4 out,
+                                                     const cpoint *__restrict__ gen_win, cpoint q7, cpoint q8, u32 *flag) {
+    static_assert(NB == 3 || NB == 4, "2 NB <= 8 denominators per pair share one inversion");
+    const size_t n_threads = (size_t)1 << (log_size - 3);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_threads) return;
+    const u32 row0 = (((u32)t >> 6) << 9) + 2u * ((u32)t & 63u);          // first row of the lane's pair 0; pair j: + 128 j
+    const cpoint p0 = cpoint_from_index_win((half_initial + __brev(row0)) & 0x7fffffffu, gen_win);
+    const cpoint p1 = cpoint_add(p0, q7), p2 = cpoint_add(p0, q8);
+    const cpoint p3 = cpoint_add(p2, q7);
+    bool zero = false;
+#pragma unroll 1          // (rolled: one copy of the body)
+    for (int j = 0; j < 4; j++) {
+        const u32 row = row0 + 128u * (u32)j;
+        const cpoint pj = j == 0 ? p0 : j == 1 ? p1 : j == 2 ? p2 : p3;
+        // ---- numerators: 8 running 64-bit sums per batch, index 2 k + r (coordinate k, row r of the pair), folded between groups of
+        //      4 column entries (x = lo + 2^32 hi = lo + 2 hi mod P: one multiply-add, see k_quotients8<., LAZY>)
+        u64 accq[NB][8];
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int s = 0; s < 8; s++) accq[b][s] = 0ull;
+        u32 two = 2u;
+        asm volatile("" : "+v"(two));
+        // The column words of a group of 4 entries are 4 loads of 8 bytes per lane — 2 KiB per wave — so the NEXT group's loads are
+        // issued before this group's multiply-adds (two register sets, the loop unrolled by two): 4 KiB per wave in flight, what the
+        // 16-byte kernels have; with one group in flight the kernel ran at half their memory rate on wide column lists.
+        auto load_group = [&](u32 (&f)[8], u32 jn) {
+            const u32 cnt = jn < n_entries ? min(4u, n_entries - jn) : 0u;          // wave-uniform; a group past the end re-reads entry 0
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const u32 je = e < (int)cnt ? jn + e : 0u;
+                const uint2 fv = gload2(lp[je], row);      // loads are never branched around
+                f[2 * e] = fv.x; f[2 * e + 1] = fv.y;
+            }
+        };
+        auto use_group = [&](u32 (&f)[8], u32 jn) {
+            const u32 cnt = min(4u, n_entries - jn);                    // wave-uniform
+            u32 cw[NB][4][4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const u32 je = jn + (e < (int)cnt ? e : 0);
+                const bool on = e < (int)cnt;
+#pragma unroll
+                for (int b = 0; b < NB; b++) {                               // same column, NB coefficient sets; unused products get c = 0
+                    const qm31 cq = lc[(u32)b * n_entries + je];
+                    cw[b][e][0] = on ? cq.a : 0u; cw[b][e][1] = on ? cq.b : 0u; cw[b][e][2] = on ? cq.c : 0u; cw[b][e][3] = on ? cq.d : 0u;
+                }
+            }
+            f8::boundary<kPrioHeavy>(f);
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const int k = s >> 1, r = s & 1;
+                    u64 a = (u64)(u32)(accq[b][s] >> 32) * (u64)two + (u64)(u32)accq[b][s];          // the fold (0 stays 0)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) a += (u64)cw[b][e][k] * (u64)f[2 * e + r];
+                    accq[b][s] = a;
+                }
+#pragma unroll
+            for (int b = 0; b < NB; b++) f8::pin(accq[b]);
+            f8::done();
+        };
+        u32 fa[8], fb[8];
+        load_group(fa, 0);
+        for (u32 jn = 0; jn < n_entries; jn += 8) {
+            load_group(fb, jn + 4);
+            use_group(fa, jn);
+            load_group(fa, jn + 8);
+            if (jn + 4 < n_entries) use_group(fb, jn + 4);
+        }
+        // ---- the pair's 2 NB denominators (element 2 b + r: batch b, row r; r = 1 is the conjugate point: y -> -y), one inversion
+        u32 ir[8], ii[8];
+        {
+            u32 xs[8], ys[8], mx[8], my[8], px[8], py[8];
+            f8::pin(accq[0]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { xs[e] = pj.x; ys[e] = pj.y; }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const BatchConst bc = batches[b < NB ? b : 0];
+                mx[b] = M31_P - bc.piy.a; mx[4 + b] = M31_P - bc.piy.b;
+                my[b] = bc.pix.a; my[4 + b] = bc.pix.b;
+            }
+            f8::mul(px, xs, mx);            // x (P - Pi.y): [re part of batch 0..3 | im part of batch 0..3]
+            f8::mul(py, ys, my);            // y Pi.x
+            u32 da[8], db[8], c8[8], tx[8], ty[8], u[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const BatchConst bc = batches[(e >> 1) < NB ? (e >> 1) : 0];
+                const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));       // wave-uniform (scalar unit)
+                c8[e] = c0.a; tx[e] = px[e >> 1]; ty[e] = py[e >> 1];
+            }
+            f8::add(u, c8, tx);
+            f8::addsub<0xAAu>(da, u, ty);           // + y Pi.x on the row with +y, - on the conjugate row
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const BatchConst bc = batches[(e >> 1) < NB ? (e >> 1) : 0];
+                const cm31 c0 = cm31_sub(cm31_mul(bc.prx, bc.piy), cm31_mul(bc.pry, bc.pix));
+                c8[e] = c0.b; tx[e] = px[4 + (e >> 1)]; ty[e] = py[4 + (e >> 1)];
+            }
+            f8::add(u, c8, tx);
+            f8::addsub<0xAAu>(db, u, ty);
+            f8::done();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (e >= 2 * NB) { da[e] = 1u; db[e] = 0u; }                          // unused slots of the inversion
+                else if ((da[e] | db[e]) == 0) { zero = true; da[e] = 1u; }
+            }
+            u64 nn[8];
+            u32 n[8], ninv[8], ndb[8];
+            f8::boundary<kPrioHeavy>(da, db);
+            f8::mul64(nn, da, da); f8::mad(nn, db, db);
+            f8::reduce<false>(n, nn);
+            f8::inverse8(ninv, n);
+            f8::neg_operand(ndb, db);
+            f8::mul(ir, da, ninv);
+            f8::mul(ii, ndb, ninv);
+        }
+        // ---- per batch: num - (A y + B), term = that x d^-1, acc = acc * coeff + term
+        u32 o[4][2];
+        if constexpr (ACCUM) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint2 v = gload2(out.p[k], row);
+                o[k][0] = v.x; o[k][1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const BatchConst bc = batches[b];
+            u32 num[8], ay[8], a8[8], y8[8], b8[8], nb[8], nq[8];
+            f8::reduce(num, accq[b]);
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int k = s >> 1;
+                a8[s] = k == 0 ? bc.A.a : k == 1 ? bc.A.b : k == 2 ? bc.A.c : bc.A.d;
+                b8[s] = k == 0 ? bc.B.a : k == 1 ? bc.B.b : k == 2 ? bc.B.c : bc.B.d;
+                y8[s] = pj.y;
+            }
+            f8::mul(ay, a8, y8);                                  // A_k y (the same for both rows; the conjugate row takes it with the other sign)
+            f8::sub(nb, num, b8);
+            f8::addsub<0x55u>(nq, nb, ay);                        // minus (+ A y) on the row with +y (even index), plus on the row with -y
+            // term = (n0 + n1 i | n2 + n3 i) (ir + ii i): index 4 h + 2 q + r (CM31 half h, part q: re / im, row r)
+            u32 U[8], V[8], W[8], Z[8], term[8];
+            const u32 P = vgpr_P();
+            f8::done();
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int h = s >> 2, q = (s >> 1) & 1, r = s & 1;
+                U[s] = nq[2 * (2 * h) + r]; W[s] = nq[2 * (2 * h + 1) + r];
+                V[s] = q == 0 ? ir[2 * b + r] : ii[2 * b + r];
+                Z[s] = q == 0 ? P - ii[2 * b + r] : ir[2 * b + r];
+            }
+            u64 a64[8];
+            f8::boundary<kPrioHeavy>(U, V, W, Z);
+            f8::mul64(a64, U, V); f8::mad(a64, W, Z);
+            f8::reduce<false>(term, a64);
+            f8::done();
+            // coordinate k of row r: term[4 (k >> 1) + 2 (k & 1) + r]
+            if (b == 0 && !ACCUM) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) o[k][r] = term[4 * (k >> 1) + 2 * (k & 1) + r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const qm31 m = qm31_mul({o[0][r], o[1][r], o[2][r], o[3][r]}, bc.coeff);
+                    o[0][r] = m31_add(m.a, term[r]); o[1][r] = m31_add(m.b, term[2 + r]);
+                    o[2][r] = m31_add(m.c, term[4 + r]); o[3][r] = m31_add(m.d, term[6 + r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) gstore2(out.p[k], row, make_uint2(o[k][0], o[k][1]));
+    }
+    if (zero) raise_flag(flag);
+}
+
 // Any log_size (used for log_size < 3): one row per lane, the reference's formulation verbatim.
 __global__ void __launch_bounds__(256) k_quotients_row(u32 half_initial, u32 log_size, const u32 *const *__restrict__ cols,
                                                       const BatchConst *__restrict__ batches, u32 n_batches,
@@ -494,7 +684,17 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
     const size_t ptr_bytes = ((n_cols * sizeof(u32 *) + 63) / 64) * 64;
     const size_t bc_bytes = ((n_batches * sizeof(BatchConst) + 63) / 64) * 64;
     const size_t en_bytes = ((n_entries * sizeof(Entry) + 63) / 64) * 64;
-    std::vector<unsigned char> blob(ptr_bytes + bc_bytes + en_bytes + 64, 0);
+    // k >= 2 batches over ONE column list (the same columns in the same order in every batch) take the shared-load kernels,
+    // which read the list as two compact tables: per position the column pointer, per batch and position the coefficient
+    bool same_list = n_batches >= 2 && !knobs().quot_no_pair && batch_off[1] > batch_off[0];
+    const u32 per = same_list ? batch_off[1] - batch_off[0] : 0;
+    for (size_t bb = 1; same_list && bb < n_batches; bb++) {
+        same_list = batch_off[bb + 1] - batch_off[bb] == per;
+        for (size_t j = 0; same_list && j < per; j++) same_list = col_idx[batch_off[0] + j] == col_idx[batch_off[bb] + j];
+    }
+    const size_t lp_bytes = same_list ? (((size_t)per * sizeof(u32 *) + 63) / 64) * 64 : 0;
+    const size_t lc_bytes = same_list ? ((n_batches * (size_t)per * sizeof(qm31) + 63) / 64) * 64 : 0;
+    std::vector<unsigned char> blob(ptr_bytes + bc_bytes + en_bytes + lp_bytes + lc_bytes + 64, 0);
     const u32 **hp = (const u32 **)blob.data();
     for (size_t i = 0; i < n_cols; i++) {
         if (((uintptr_t)cols[i]) & 15) return set_error(TSTWO_ERR_BAD_ARG, "quotients: columns must be 16-byte aligned");
@@ -520,6 +720,13 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         x.begin = batch_off[b];
         x.end = batch_off[b + 1];
     }
+    if (same_list) {
+        const u32 **hlp = (const u32 **)(blob.data() + ptr_bytes + bc_bytes + en_bytes);
+        qm31 *hlc = (qm31 *)(blob.data() + ptr_bytes + bc_bytes + en_bytes + lp_bytes);
+        for (size_t j = 0; j < per; j++) hlp[j] = cols[col_idx[batch_off[0] + j]];
+        for (size_t bb = 0; bb < n_batches; bb++)
+            for (size_t j = 0; j < per; j++) hlc[bb * per + j] = he[batch_off[bb] + j].c;
+    }
     int rc = ensure_scratch(blob.size());
     if (rc) return rc;
     rc = small_h2d(c.scratch, blob.data(), blob.size());   // stream-ordered: nothing in flight still reads the scratch when it lands
@@ -527,6 +734,8 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
     const u32 *const *d_cols = (const u32 *const *)c.scratch;
     const BatchConst *d_b = (const BatchConst *)((unsigned char *)c.scratch + ptr_bytes);
     const Entry *d_e = (const Entry *)((unsigned char *)c.scratch + ptr_bytes + bc_bytes);
+    const u32 *const *d_lp = (const u32 *const *)((unsigned char *)c.scratch + ptr_bytes + bc_bytes + en_bytes);
+    const qm31 *d_lc = (const qm31 *)((unsigned char *)c.scratch + ptr_bytes + bc_bytes + en_bytes + lp_bytes);
     Soa4 o4 = {{out[0], out[1], out[2], out[3]}};
     bool aligned = true;
     for (int k = 0; k < 4; k++) aligned = aligned && ((((uintptr_t)out[k]) & 15) == 0);
@@ -541,22 +750,34 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
         for (size_t b = 0; b < n_batches; b++) lazy = lazy || (!no_lazy && batch_off[b + 1] - batch_off[b] > 4);
         const dim3 grid(ceil_div(n_threads, 256));
         // two batches over one column list (same columns in the same order): the column words are loaded once for both
-        const bool no_pair = knobs().quot_no_pair;          // (A/B timing)
-        // k >= 2 batches over ONE column list (the same columns in the same order in every batch): sweeps of 3 or 2 batches, the later
-        // sweeps continuing from the rows the earlier ones wrote (k = 2: 2; 3: 3; 4: 2 + 2; 5: 3 + 2; ...)
-        bool pair = n_batches >= 2 && !no_pair && batch_off[1] > batch_off[0];
-        const u32 per = pair ? batch_off[1] - batch_off[0] : 0;
-        for (size_t bb = 1; pair && bb < n_batches; bb++) {
-            pair = batch_off[bb + 1] - batch_off[bb] == per;
-            for (size_t j = 0; pair && j < per; j++) pair = col_idx[batch_off[0] + j] == col_idx[batch_off[bb] + j];
-        }
+        const bool pair = same_list;
         if (pair) {
             size_t done = 0;
+            // sweeps: 2 batches -> k_quotients8_multi<2>; 3 or 4 -> the row-pair kernel k_quotients_rp<3 | 4> (log_size >= 9);
+            // more -> 4 (or 3) at a time, the later sweeps continuing from the rows the earlier ones wrote (5 = 3 + 2, 6 = 3 + 3, 7 = 4 + 3)
+            const bool rp_ok = log_size >= 9 && !knobs().quot_no_rowpair;
+            u32 q7x, q7y, q8x, q8y;
+            host::point(1u << 24, &q7x, &q7y);
+            host::point(1u << 23, &q8x, &q8y);
+            const cpoint q7 = {q7x, q7y}, q8 = {q8x, q8y};
             while (done < n_batches) {
                 const size_t left = n_batches - done;
+                if (rp_ok && left >= 3) {
+                    const int nb = (left == 3 || left == 5 || left == 6) ? 3 : 4;
+#define TSTWO_QRP(NBV, ACC) hipLaunchKernelGGL((k_quotients_rp<NBV, ACC>), grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, \
+                                               d_lp, d_b + done, d_lc + done * per, per, o4, c.gen_win, q7, q8, c.flag)
+                    if (nb == 3 && done == 0) TSTWO_QRP(3, false);
+                    else if (nb == 3) TSTWO_QRP(3, true);
+                    else if (done == 0) TSTWO_QRP(4, false);
+                    else TSTWO_QRP(4, true);
+#undef TSTWO_QRP
+                    TSTWO_LAUNCH_CHECK();
+                    done += (size_t)nb;
+                    continue;
+                }
                 const int nb = knobs().quot_no_triple ? (left >= 2 ? 2 : 1) : ((left == 2 || left == 4) ? 2 : 3);
 #define TSTWO_QMULTI(NBV, ACC) hipLaunchKernelGGL((k_quotients8_multi<NBV, ACC>), grid, dim3(256), 0, c.stream, half_initial & 0x7fffffffu, log_size, \
-                                                  d_cols, d_b + done, d_e, o4, c.gen_win, qb, bsel, c.flag)
+                                                  d_lp, d_b + done, d_lc + done * per, per, o4, c.gen_win, qb, bsel, c.flag)
                 if (nb == 1) TSTWO_QMULTI(1, true);
                 else if (nb == 2 && done == 0) TSTWO_QMULTI(2, false);
                 else if (nb == 2) TSTWO_QMULTI(2, true);
