@@ -479,12 +479,18 @@ def main():
         for h in cols_host:
             L.host_register(h)
         t_reg = time.perf_counter() - t0
-        L.sync()
-        t0 = time.perf_counter()
-        for h, b in zip(cols_host, dev_cols):
-            b.upload_async(h)
-        L.upload_wait()
-        t_pin = time.perf_counter() - t0
+        # (the FIRST copy out of freshly registered memory also pays for mapping its pages into the device: 37 GB/s on a box whose
+        # steady rate is 55 — both are reported, the steady one is the rate of the hand-over)
+        t_pin_first = None
+        for attempt in range(2):
+            L.sync()
+            t0 = time.perf_counter()
+            for h, b in zip(cols_host, dev_cols):
+                b.upload_async(h)
+            L.upload_wait()
+            t_pin = time.perf_counter() - t0
+            if t_pin_first is None:
+                t_pin_first = t_pin
 
         def step_from_host():
             for c in range(tree_cols):
@@ -515,6 +521,7 @@ def main():
         for h in cols_host:
             L.host_unregister(h)
         host_legs = {"register_seconds": t_reg, "h2d_seconds_registered": t_pin, "h2d_GBps_registered": 4.0 * N * n_cols / t_pin / 1e9,
+                     "h2d_GBps_registered_first_pass": 4.0 * N * n_cols / t_pin_first / 1e9,
                      "pipelined_step_ms": t_pipe * 1e3, "upload_alone_ms": t_pin * 1e3, "compute_alone_ms": t_comp * 1e3,
                      "pipelined_over_max": t_pipe / max(t_pin, t_comp), "roots_match_resident_step": roots_from_host == gpu_roots_first,
                      "pcie_inclusive_elems_per_s_pipelined": n_cols * N / t_pipe,

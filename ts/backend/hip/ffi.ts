@@ -3,7 +3,7 @@
 // Intended location in tstwo: packages/core/src/backend/hip/ffi.ts.  NOT TESTED in the build image (no Bun there);
 // the same ABI, call for call, is exercised by tstwo_amd/_lib.py (ctypes) in every `-m gpu` test of this repository.
 // Device pointers travel as u64 (bigint); `P` arguments are host typed arrays (ptr(...)).
-import { dlopen, FFIType, ptr } from "bun:ffi";
+import { dlopen, FFIType, ptr, toArrayBuffer } from "bun:ffi";
 
 const { i32, u32, u64, ptr: P, cstring } = FFIType;
 
@@ -146,8 +146,34 @@ export class DeviceBuffer {
     if (count) check(hip.tstwo_download(ptr(out), this.dev + BigInt(byteOffset), BigInt(count)));
     return out;
   }
+  /** tstwo_upload_async: the copy runs on the library's copy streams beside the kernels.  `words` should be page-locked (PinnedU32
+   *  or hostRegister) and must stay alive and unchanged until uploadWait() / tstwo_sync. */
+  uploadAsync(words: Uint32Array, byteOffset = 0): void {
+    if (words.byteLength) check(hip.tstwo_upload_async(this.dev + BigInt(byteOffset), ptr(words), BigInt(words.byteLength)));
+  }
   free(): void { check(hip.tstwo_free(this.dev)); }
 }
+
+/** Host hand-over beside the kernels (createBaseFieldColumn(data), backend/index.ts:20-31): page-lock a typed array the caller owns ... */
+export function hostRegister(words: Uint32Array): void { ensureInit(); check(hip.tstwo_host_register(ptr(words), BigInt(words.byteLength))); }
+export function hostUnregister(words: Uint32Array): void { check(hip.tstwo_host_unregister(ptr(words))); }
+/** ... or take page-locked memory from the library: `view` is a Uint32Array over it. */
+export class PinnedU32 {
+  readonly view: Uint32Array;
+  private addr: number;
+  constructor(count: number) {
+    ensureInit();
+    const out = new BigUint64Array(1);
+    check(hip.tstwo_host_alloc(ptr(out), BigInt(4 * count)));
+    this.addr = Number(out[0]!);
+    this.view = new Uint32Array(toArrayBuffer(this.addr as any, 0, 4 * count));
+  }
+  free(): void { check(hip.tstwo_host_free(this.addr as any)); }
+}
+/** Main-stream work enqueued after this call waits (on the device) for the copies issued so far; the host does not block. */
+export function uploadFence(): void { check(hip.tstwo_upload_fence()); }
+/** The host blocks until the copies issued so far have landed (their sources may be reused). */
+export function uploadWait(): void { check(hip.tstwo_upload_wait()); }
 
 /** Several small device buffers in ONE round trip (tstwo_download_many): pieces = [device address, words]. */
 export function downloadMany(pieces: readonly (readonly [bigint, number])[]): Uint32Array[] {
