@@ -203,10 +203,13 @@ def case_quotients():
     """accumulateQuotients through the host mirror (quotientConstants + kernel) == the oracle's per-row reference formulation."""
     n = int(rng.integers(1, 13))
     n_cols = int(rng.integers(1, 9))
-    cols = [rcol(1 << n) for _ in range(n_cols)]
     n_batches = int(rng.integers(1, 4))
     batches_o, batches_t = [], []
     shared = rng.choice(n_cols, size=int(rng.integers(1, n_cols + 1)), replace=False) if rng.integers(0, 3) == 0 else None
+    if shared is not None and rng.integers(0, 2) == 0:
+        n_batches = int(rng.integers(2, 10))          # round 4: 3+ batches over one list take the row-pair / multi-batch sweeps (n >= 9: k_quotients_rp)
+        n = max(n, int(rng.integers(3, 13)))
+    cols = [rcol(1 << n) for _ in range(n_cols)]
     for _ in range(n_batches):
         pt = _rand_secure_point()
         # one time in three every batch covers the same columns in the same order (each column opened at several points: with two

@@ -561,6 +561,40 @@ def test_cfft_evaluate_extended_matches_extend_then_evaluate(log_poly, log_size)
         assert (out[0].download() == orc.cfft_evaluate(ext, log_size, half, otw, log_size - 1)).all()
 
 
+@pytest.mark.parametrize("log_poly,log_size,n_cols", [(20, 22, 8), (21, 22, 8), (21, 23, 4), (22, 23, 4), (20, 22, 5)])
+def test_cfft_wide_plans_on_the_2_15_tile_fused_and_out_of_place(log_poly, log_size, n_cols):
+    """From 4 columns (n = 22) / 2 columns (n = 23) on, the default plan puts the strided pass on the 2^15-word tile (13 + 9 /
+    13 + 10): the fused extension (k_cfft_a<false, K, EXT, 15>) against extend + evaluate, that evaluation against the oracle on
+    one column, and the out-of-place interpolate back to the zero-padded coefficients."""
+    half = 1 << (31 - (log_size + 1))
+    tw, itw = L.DeviceBuffer(4 << (log_size - 1)), L.DeviceBuffer(4 << (log_size - 1))
+    L.call("tstwo_twiddles_build", half, log_size - 1, vp(tw), vp(itw))
+    polys = [rand_column(31000 + 11 * log_size + c, 1 << log_poly) for c in range(n_cols)]
+    src = [dev(p_) for p_ in polys]
+    ref = [L.DeviceBuffer(4 << log_size) for _ in polys]
+    for s_, r in zip(src, ref):
+        L.call("tstwo_poly_extend", vp(s_), log_poly, vp(r), log_size)
+    L.call("tstwo_cfft_evaluate", L.ptr_array([r.ptr for r in ref]), n_cols, log_size, half, vp(tw), log_size - 1)
+    out = [L.DeviceBuffer(4 << log_size) for _ in polys]
+    L.call("tstwo_cfft_evaluate_extended", L.ptr_array([s_.ptr for s_ in src]), log_poly, L.ptr_array([o.ptr for o in out]), n_cols,
+           log_size, half, vp(tw), log_size - 1)
+    for o, r in zip(out, ref):
+        assert (o.download() == r.download()).all()
+    otw, _ = orc.precompute_twiddles(half, log_size - 1, inverse=False)
+    padded = np.zeros(1 << log_size, dtype=np.uint32)
+    padded[:1 << log_poly] = polys[n_cols - 1]
+    assert (out[n_cols - 1].download() == orc.cfft_evaluate(padded, log_size, half, otw, log_size - 1)).all()
+    back = [L.DeviceBuffer(4 << log_size) for _ in polys]
+    L.call("tstwo_cfft_interpolate_to", L.ptr_array([o.ptr for o in out]), L.ptr_array([b.ptr for b in back]), n_cols, log_size, half,
+           vp(itw), log_size - 1)
+    for b, p_ in zip(back, polys):
+        got = b.download()
+        assert (got[:1 << log_poly] == p_).all() and not got[1 << log_poly:].any()
+    n_passes = C.c_uint32(0)
+    L.call("tstwo_cfft_plan_passes", log_size, n_cols, C.byref(n_passes))
+    assert n_passes.value == 2
+
+
 def test_cfft_evaluate_extended_errors():
     tw = L.DeviceBuffer(4 << 12)
     L.call("tstwo_twiddles_build", 1 << (31 - 14), 12, vp(tw), vp(None))
