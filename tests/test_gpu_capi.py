@@ -972,6 +972,9 @@ def test_shipped_library_ignores_the_experiment_knobs():
     out = subprocess.run([sys.executable, "-c", script], env=dict(env, TSTWO_HIP_LIB=L.LIB_EXP_PATH, TSTWO_CFFT_KB="12"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines()[-1].rsplit(" ", 1)[1] == want          # a plan-changing knob alone: same results
+    out = subprocess.run([sys.executable, "-c", script], env=dict(env, TSTWO_HIP_LIB=L.LIB_EXP_PATH, TSTWO_CFFT_B8="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1].rsplit(" ", 1)[1] == want          # the 8-words-per-lane bottom pass (measured, not shipped): same results
 
 
 @pytest.mark.parametrize("shape", [(4, 32, 17), (8, 32, 18), (3, 16, 19), (2, 64, 17), (5, 48, 17), (2, 32, 12), (1, 32, 17), (3, 20, 17)], ids=str)

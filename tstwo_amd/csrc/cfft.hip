@@ -77,7 +77,7 @@ __device__ __forceinline__ void ibf_dbl(u32 &v0, u32 &v1, u32 t2) {
 // heavy as well) — the caller drops to kPrioLight after its last layer.
 template <bool INV, int N>
 __device__ __forceinline__ void bf_layer(u32 (&x)[N], u32 (&y)[N], const u32 (&t2)[N]) {
-    static_assert(N == 8, "phase() pins 8 or 16 values");
+    static_assert(N == 8 || N == 4, "phase() pins 4, 8 or 16 values");
     const u32 P = vgpr_P();
     u32 s[N], d[N], u[N], w[N], u2[N], w2[N];
     u64 p[N];
@@ -555,7 +555,13 @@ int launch_fast(u32 *const *cols, size_t n_cols, u32 n, const Pass &ps, const u3
         const size_t lds = (((size_t)1 << ps.k) + ((size_t)1 << (ps.k - 5)) + ((size_t)1 << (ps.k - 4))) * sizeof(u32);
         switch (ps.k) {
             case 14: return launch_fast_kernel(fast::k_cfft_b<INV, 14>, 1024, lds, tiles, cols, n_cols, n, tw_end, scale);
-            case 13: return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale);
+            case 13:
+#ifdef TSTWO_EXPERIMENTS      // TSTWO_CFFT_B8=1: the 8-words-per-lane bottom pass (1024 lanes, 8 waves per SIMD)
+                if (knobs().cfft_b8)
+                    return launch_fast_kernel(fast::k_cfft_b8<INV, 13>, 1024, (((size_t)1 << 13) + ((size_t)1 << 8) + ((size_t)1 << 10)) * sizeof(u32), tiles, cols,
+                                              n_cols, n, tw_end, scale);
+#endif
+                return launch_fast_kernel(fast::k_cfft_b<INV, 13>, 512, lds, tiles, cols, n_cols, n, tw_end, scale);
             case 12: return launch_fast_kernel(fast::k_cfft_b<INV, 12>, 256, lds, tiles, cols, n_cols, n, tw_end, scale);
             case 11: return launch_fast_kernel(fast::k_cfft_b<INV, 11>, 128, lds, tiles, cols, n_cols, n, tw_end, scale);
             default: return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported bottom pass");

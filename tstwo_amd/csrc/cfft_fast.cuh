@@ -70,15 +70,18 @@ __device__ __forceinline__ void groups_layers(u32 (&v)[NG][1 << G], const u32 *t
 }
 
 // In-place LDS stage: every lane handles 16 >> G groups of 2^G words.
-template <int G, int Q, int LOGT, int THREADS, bool INV>
+template <int G, int Q, int LOGT, int THREADS, bool INV, int WPL = 16>
 __device__ __forceinline__ void lds_stage(u32 *lds, const u32 *twl, u32 tid) {
-    constexpr int NG = 16 >> G;
+    constexpr int NG = WPL >> G;
     u32 v[NG][1 << G], high[NG];
     u32 *p[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         u32 gid = tid + (u32)g * THREADS;
         if (Q == 4) gid = (gid & ~0x30u) | ((gid & 0x10u) << 1) | ((gid & 0x20u) >> 1);   // bank-conflict-free lane -> group map
+        // (Q = 3, the 8-words-per-lane kernel: the word address is 33 high + low + const, so 32 lanes need distinct high + low mod 32:
+        // lane bits 3, 4 go to high bits 3, 4 and lane bits 5..7 to high bits 0..2 — banks 8 a + low + const)
+        if (Q == 3) gid = (gid & ~0xF8u) | (((gid >> 3) & 3u) << 6) | (((gid >> 5) & 7u) << 3);
         const u32 low = gid & ((1u << Q) - 1u);
         high[g] = gid >> Q;
         p[g] = lds + pad((high[g] << (Q + G)) | low);
@@ -332,6 +335,171 @@ __global__ void __launch_bounds__(1 << (LOGT - 4), TSTWO_B_WAVES) k_cfft_b(ColPt
     }
     }   // runs of one tile
 }
+
+#ifdef TSTWO_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------
+// Bottom pass with 8 words per lane (experiments build only; the round-3 verdict's "one structural attempt"): a 2^LOGT tile on
+// 2^(LOGT-3) lanes — 1024 at LOGT = 13, two workgroups per CU = 8 waves per SIMD where k_cfft_b has 6 — at the price of five
+// exchanges of 8 words where k_cfft_b has 3.5 of 16: layers LOGT-1, LOGT-2 in registers on four 8-byte loads a quarter-tile apart |
+// LOGT-3..LOGT-5 | LOGT-6..LOGT-8 | 4, 3 (two groups of 4 words per lane) | 2, 1, 0 on the lane's 8 consecutive words, stored as
+// two 16-byte pieces.  4 butterflies per lane and layer: priority phases of 4.  In place only.  Measured: DESIGN.md 4.1.
+template <bool INV, int LOGT>
+__global__ void __launch_bounds__(1 << (LOGT - 3), 8) k_cfft_b8(ColPtrs cols, NoSrc, u32 n_cols, u32 total_items, u32 n,
+                                                                const u32 *__restrict__ tw_end, u32 scale) {
+    static_assert(LOGT == 13, "stage bits below are written for the 2^13 tile");
+    constexpr int THREADS = 1 << (LOGT - 3);
+    constexpr u32 T = 1u << LOGT, QT = T / 4;
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    u32 *twl = lds + T + T / 32;                          // 2^(LOGT-3)-entry heap: layer bits 3..LOGT-3
+    const u32 t = threadIdx.x;
+    const u32 share = total_items / gridDim.x, extra = total_items % gridDim.x;
+    u32 item = blockIdx.x * share + min(blockIdx.x, extra);
+    const u32 item_end = item + share + (blockIdx.x < extra ? 1u : 0u);
+#pragma unroll 1
+    while (item < item_end) {
+    const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(item / n_cols));   // tile index
+    const u32 col0 = item - hi * n_cols;
+    const u32 col1 = min(n_cols, col0 + (item_end - item));
+    item += col1 - col0;
+    const size_t base = (size_t)hi << LOGT;
+    uint2 pf2[4];           // forward: four 8-byte pieces a quarter-tile apart
+    uint4 pf4[2];           // inverse: the lane's 8 consecutive words
+    u32 t1[2], t2, ta, tb0, tb1;
+    {
+        const u32 *__restrict__ d = colp_u(cols, col0) + base;
+        if (!INV) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) pf2[j] = gload2(d, 2 * t + j * QT);
+        } else {
+            pf4[0] = gload4(d, 8 * t); pf4[1] = gload4(d, 8 * t + 4);
+        }
+        const uint2 q1 = gload2(tw_end - ((size_t)1 << (n - 1)) + ((size_t)hi << (LOGT - 2)), 2 * t);        // layer 1: h = idx >> 2 = 2 t, 2 t + 1
+        const u32 q2 = gload1(tw_end - ((size_t)1 << (n - 2)) + ((size_t)hi << (LOGT - 3)), t);              // layer 2: h = t
+        const u32 th = max(t, 4u);
+        const u32 lv = 31u - (u32)__clz(th);
+        const u32 hb = (u32)(LOGT - 1) - lv;                                                                   // heap: layer bit hb in 3..LOGT-3
+        const u32 hoff = (1u << (n - 3)) - (1u << (n - hb)) + (hi << lv) + (th - (1u << lv));
+        const u32 hv = gload1(tw_end - ((size_t)1 << (n - 3)), hoff);
+        const u32 a = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 1))) + (ptrdiff_t)hi];
+        const u32 b0 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi)];
+        const u32 b1 = tw_end[-(ptrdiff_t)((size_t)1 << (n - (LOGT - 2))) + (ptrdiff_t)(2 * (size_t)hi + 1)];
+        t1[0] = q1.x + q1.x; t1[1] = q1.y + q1.y; t2 = q2 + q2;
+        if (t >= 4) twl[t] = hv + hv;
+        ta = a + a; tb0 = b0 + b0; tb1 = b1 + b1;
+    }
+    lds_barrier();          // heap visible before any stage reads it
+    // the three lowest layers on 8 consecutive words: layer 2 (t2), layer 1 (t1[2]), circle layer (t1 permuted / negated)
+    auto low3 = [&](u32 (&v)[8]) {
+        u32 tc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            tc[j] = t1[(j >> 1) ^ 1];
+            if ((j ^ (j >> 1)) & 1) tc[j] = 0xFFFFFFFEu - tc[j];
+        }
+#pragma unroll
+        for (int step = 0; step < 3; step++) {
+            const int l = INV ? step : 2 - step;
+            u32 x[4], y[4], tw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = ((i >> l) << (l + 1)) | (i & ((1 << l) - 1));
+                x[i] = v[m]; y[i] = v[m + (1 << l)];
+                tw[i] = l == 0 ? tc[m >> 1] : l == 1 ? t1[m >> 2] : t2;
+            }
+            bf_layer<INV, 4>(x, y, tw);
+            if (step == 2) phase<kPrioLight>(x, y);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = ((i >> l) << (l + 1)) | (i & ((1 << l) - 1));
+                v[m] = x[i]; v[m + (1 << l)] = y[i];
+            }
+        }
+    };
+    // the two top layers on the four quarter-tile pairs w[2 j], w[2 j + 1]: layer LOGT-1 pairs quarters (0, 2), (1, 3) with ta;
+    // layer LOGT-2 pairs (0, 1) with tb0, (2, 3) with tb1
+    auto top2 = [&](u32 (&w)[8]) {
+#pragma unroll
+        for (int step = 0; step < 2; step++) {
+            const bool top = INV ? step == 1 : step == 0;
+            u32 x[4], y[4], tw[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // butterfly i: component i & 1 of quarter pair (i >> 1)
+                const int qa = top ? (i >> 1) : 2 * (i >> 1), qb = top ? qa + 2 : qa + 1;
+                x[i] = w[2 * qa + (i & 1)]; y[i] = w[2 * qb + (i & 1)];
+                tw[i] = top ? ta : ((i >> 1) ? tb1 : tb0);
+            }
+            bf_layer<INV, 4>(x, y, tw);
+            if (step == 1) phase<kPrioLight>(x, y);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int qa = top ? (i >> 1) : 2 * (i >> 1), qb = top ? qa + 2 : qa + 1;
+                w[2 * qa + (i & 1)] = x[i]; w[2 * qb + (i & 1)] = y[i];
+            }
+        }
+    };
+    for (u32 col = col0; col < col1; col++) {
+        u32 *__restrict__ data = colp_u(cols, col) + base;
+        const u32 *__restrict__ next = colp_u(cols, min(col + 1, col1 - 1)) + base;
+        u32 tt = t;
+        asm volatile("" : "+v"(tt));
+        if (!INV) {
+            u32 w[8] = {pf2[0].x, pf2[0].y, pf2[1].x, pf2[1].y, pf2[2].x, pf2[2].y, pf2[3].x, pf2[3].y};
+            top2(w);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u32 *p = lds + pad(2 * tt) + j * (QT + QT / 32);
+                p[0] = w[2 * j]; p[1] = w[2 * j + 1];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; j++) pf2[j] = gload2(next, 2 * t + j * QT);
+            lds_stage<3, LOGT - 5, LOGT, THREADS, false, 8>(lds, twl, tt);       // layers LOGT-3 .. LOGT-5
+            lds_barrier();
+            lds_stage<3, LOGT - 8, LOGT, THREADS, false, 8>(lds, twl, tt);       // layers LOGT-6 .. LOGT-8
+            lds_barrier();
+            lds_stage<2, 3, LOGT, THREADS, false, 8>(lds, twl, tt);              // layers 4, 3
+            lds_barrier();
+            u32 v[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) v[m] = lds[pad(8 * tt) + m];
+            lds_barrier();       // last LDS access of this column
+            low3(v);
+            gstore4(data, 8 * t, make_uint4(v[0], v[1], v[2], v[3]));
+            gstore4(data, 8 * t + 4, make_uint4(v[4], v[5], v[6], v[7]));
+        } else {
+            u32 v[8] = {pf4[0].x, pf4[0].y, pf4[0].z, pf4[0].w, pf4[1].x, pf4[1].y, pf4[1].z, pf4[1].w};
+            low3(v);
+#pragma unroll
+            for (int m = 0; m < 8; m++) lds[pad(8 * tt) + m] = v[m];
+            lds_barrier();
+            pf4[0] = gload4(next, 8 * t); pf4[1] = gload4(next, 8 * t + 4);
+            lds_stage<2, 3, LOGT, THREADS, true, 8>(lds, twl, tt);
+            lds_barrier();
+            lds_stage<3, LOGT - 8, LOGT, THREADS, true, 8>(lds, twl, tt);
+            lds_barrier();
+            lds_stage<3, LOGT - 5, LOGT, THREADS, true, 8>(lds, twl, tt);
+            lds_barrier();
+            u32 w[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 *p = lds + pad(2 * tt) + j * (QT + QT / 32);
+                w[2 * j] = p[0]; w[2 * j + 1] = p[1];
+            }
+            lds_barrier();       // last LDS access of this column
+            top2(w);
+            if (scale) {
+                mul8_dbl(w, scale + scale);
+                phase<kPrioLight>(w);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) gstore2(data, 2 * t + j * QT, make_uint2(w[2 * j], w[2 * j + 1]));
+        }
+    }
+    lds_barrier();       // the stages read the twiddle heap: the next run restages it
+    }   // runs of one tile
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Strided pass: K layers [lo, lo+K) on a tile of 2^K rows x 2^C words (C = LOGT - K).

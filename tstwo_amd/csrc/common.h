@@ -59,6 +59,7 @@ struct Knobs {
     int cfft_lds_pad = 0;              // TSTWO_CFFT_LDS_PAD: extra dynamic LDS per workgroup (lowers residency)
     int cfft_kb = 0, cfft_ka = 0;      // TSTWO_CFFT_KB (11-15) / TSTWO_CFFT_KA (1-10): bottom tile / strided layer limit (0 = planner)
     int cfft_logta = 0;                // TSTWO_CFFT_LOGTA (12-15): strided tile (0 = planner)
+    bool cfft_b8 = false;              // TSTWO_CFFT_B8: the 8-words-per-lane bottom pass k_cfft_b8 (in-place transforms with a 2^13 bottom tile)
     int cfft_av = 0;                   // TSTWO_CFFT_AV=2: 2^14-word strided tiles on 512 lanes x 32 words (two workgroups per CU)
     int cfft_generic = 0;              // TSTWO_CFFT_GENERIC: bit 0 / 1 generic kernel for bottom / strided passes, bit 2 SKIP the bottom pass
     int cfft_group = 0;                // TSTWO_CFFT_GROUP: Infinity-Cache column grouping

@@ -29,6 +29,7 @@ static Knobs read_knobs() {
     k.cfft_ka = num("TSTWO_CFFT_KA", 0); if (k.cfft_ka < 1 || k.cfft_ka > 10) k.cfft_ka = 0;
     k.cfft_logta = num("TSTWO_CFFT_LOGTA", 0); if (k.cfft_logta < 12 || k.cfft_logta > 15) k.cfft_logta = 0;
     k.cfft_av = num("TSTWO_CFFT_AV", 0);
+    k.cfft_b8 = on("TSTWO_CFFT_B8");
     k.cfft_generic = num("TSTWO_CFFT_GENERIC", 0);
     k.cfft_group = num("TSTWO_CFFT_GROUP", 0);
     k.cfft_trace = on("TSTWO_CFFT_TRACE"); k.cfft_sync = on("TSTWO_CFFT_SYNC");

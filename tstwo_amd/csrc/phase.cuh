@@ -55,6 +55,18 @@ __device__ __forceinline__ void phase(u32 (&a)[8], u32 (&b)[8]) {
     TSTWO_SCHED_FENCE();
 }
 template <int PRIO, class T>
+__device__ __forceinline__ void phase(T (&a)[4]) {
+    TSTWO_SCHED_FENCE();
+    asm volatile("s_setprio %4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "i"(PRIO));
+    TSTWO_SCHED_FENCE();
+}
+template <int PRIO>
+__device__ __forceinline__ void phase(u32 (&a)[4], u32 (&b)[4]) {
+    TSTWO_SCHED_FENCE();
+    asm volatile("s_setprio %8" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "i"(PRIO));
+    TSTWO_SCHED_FENCE();
+}
+template <int PRIO, class T>
 __device__ __forceinline__ void phase(T (&a)[6]) {
     TSTWO_SCHED_FENCE();
     asm volatile("s_setprio %6" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "i"(PRIO));
