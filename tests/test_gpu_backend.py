@@ -660,6 +660,36 @@ def test_commitment_scheme_prover_roundtrip():
     T.MerkleVerifier(T.Blake2sMerkleHasher(), oroot, [LOG + BLOW] * 5 + [LOG - 2 + BLOW] * 2).verify(queries, values, dec)
 
 
+def test_commitment_scheme_commit_many_equals_commit_per_tree():
+    """CommitmentSchemeProver.commit_many (the trees of one phase: one batched evaluation, tstwo_merkle_commit_many, mix_root per
+    tree in order) == one commit() per tree: same evaluations, roots and channel state, for equally shaped trees (shared launches)
+    and for trees of different shapes and mixed column sizes (tree-by-tree fallback inside the library)."""
+    BLOW = 1
+    tw = T.precompute_twiddles(T.CanonicCoset(18 + BLOW).circleDomain().halfCoset)
+    for shapes in ([[17] * 16, [17] * 16, [17] * 16], [[12, 12, 10], [9], [12, 11, 11, 11, 8]]):
+        polys = [[T.HipCirclePoly(T.HipColumn(rand_column(15000 + 100 * ti + c, 1 << lg))) for c, lg in enumerate(logs)] for ti, logs in enumerate(shapes)]
+        a, b = T.CommitmentSchemeProver(BLOW, tw), T.CommitmentSchemeProver(BLOW, tw)
+        cha, chb = T.Blake2sChannel(), T.Blake2sChannel()
+        a.commit_many(polys, cha)
+        for ps in polys:
+            b.commit(ps, chb)
+        assert a.roots() == b.roots() and cha.digest() == chb.digest()
+        for ta, tb_ in zip(a.trees, b.trees):
+            for ea, eb in zip(ta.evaluations, tb_.evaluations):
+                assert ea.domain.log_size() == eb.domain.log_size() and (ea.values.to_numpy() == eb.values.to_numpy()).all()
+        # and against the oracle for the first tree
+        logs = shapes[0]
+        exp = []
+        for p_, lg in zip(polys[0], logs):
+            big = lg + BLOW
+            hb = T.CanonicCoset(big).circleDomain().halfCoset.initial_index.value
+            otw, _ = orc.precompute_twiddles(hb, big - 1, inverse=False)
+            ext = np.concatenate([p_.coeffs.to_numpy(), np.zeros((1 << big) - (1 << lg), dtype=np.uint32)])
+            exp.append(orc.cfft_evaluate(ext, big, hb, otw, big - 1))
+        _, oroot = orc.merkle_commit(exp, [lg + BLOW for lg in logs])
+        assert a.roots()[0] == oroot
+
+
 def _pcs_setup(config, col_logs_per_tree, seed=11000):
     """Commit trees of random trace columns (evaluations on canonic trace domains) the way a stwo prover does."""
     blow = config.fri_config.log_blowup_factor
