@@ -1058,8 +1058,8 @@ def test_download_many_errors():
 @pytest.mark.parametrize("log,n_cols", [(3, 2), (9, 5), (10, 4), (12, 9), (14, 33)])
 def test_quotients_two_batches_over_one_column_list(log, n_cols, golden):
     """Every column opened at two points (two sample batches over the same column list): the kernel that loads the column words
-    once for both batches (k_quotients8_pair) against the oracle's per-row reference loop — and the same input with the second
-    batch's columns in another order, which takes the general kernel."""
+    once for both batches (k_quotients8_multi<2>) against the oracle's per-row reference loop — and the same input with the second
+    batch's columns in another order (same union list: still one sweep)."""
     px, py = golden["eval_at_point"][0]["point"]
     py2 = OL.orc_qm31_mul(orc.q(py), orc.q(py)).tup()
     cols = [rand_column(9100 + 7 * log + c, 1 << log) for c in range(n_cols)]
@@ -1086,8 +1086,8 @@ def test_quotients_two_batches_over_one_column_list(log, n_cols, golden):
 def test_quotients_k_batches_over_one_column_list(log, n_cols, k, golden):
     """Every column opened at k points (k sample batches over the SAME column list): sweeps of 3 or 2 batches that load the column
     words once per sweep and continue from the rows the previous sweep wrote (k_quotients8_multi<NB, ACCUM>), against the oracle's
-    per-row reference loop; and the same input with ONE batch's columns in another order, which must take the general kernel and
-    give the oracle's rows as well."""
+    per-row reference loop; and the same input with ONE batch's columns in another order (served from the union list, by column
+    identity), which must give the oracle's rows as well."""
     px, py = golden["eval_at_point"][0]["point"]
     pts = [(px, py)]
     for _ in range(k - 1):                                   # further points on the QM31 circle: repeated doubling
@@ -1119,6 +1119,45 @@ def test_quotients_k_batches_over_one_column_list(log, n_cols, k, golden):
         exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (5, 6, 7, 8), batches)
         for c in range(4):
             assert (host(out[c], 1 << log) == exp[c]).all(), (log, n_cols, k, permuted, c)
+
+
+@pytest.mark.parametrize("log,n_cols", [(10, 8), (12, 33), (6, 5)])
+def test_quotients_batches_over_overlapping_column_lists(log, n_cols, golden):
+    """Batches whose column lists overlap without being equal — every column at the first point, every second one also at a
+    second point, a few (one of them listed twice) at a third — are served from the UNION list with zero coefficients where a
+    batch does not sample a column; rows must equal the oracle's per-row reference loop.  Disjoint lists (below the 1.4 entries per
+    union column the library asks for) take the per-batch kernel and must give the oracle's rows too."""
+    px, py = golden["eval_at_point"][0]["point"]
+    py2 = OL.orc_qm31_mul(orc.q(py), orc.q(py)).tup()
+    pts = [(px, py), (py, py2), (py2, px)]
+    cols = [rand_column(9300 + 7 * log + c, 1 << log) for c in range(n_cols)]
+    d = [dev(c) for c in cols]
+    val = lambda j: tuple(int(x) for x in rand_column(9400 + 3 * log + j, 4))
+    lists = {
+        "overlap": [list(range(n_cols)), list(range(0, n_cols, 2)), [n_cols - 1, 1, 1, 0]],
+        "disjoint": [list(range(0, n_cols // 2)), list(range(n_cols // 2, n_cols))],
+    }
+    for name, ls in lists.items():
+        batches, j = [], 0
+        for b, cl in enumerate(ls):
+            cv = []
+            for c in cl:
+                cv.append((c, val(j)))
+                j += 1
+            batches.append((pts[b][0], pts[b][1], cv))
+        off, cidx, points, values = [0], [], [], []
+        for bx, by, cv in batches:
+            points += [*bx, *by]
+            for ci, v in cv:
+                cidx.append(ci)
+                values += list(v)
+            off.append(len(cidx))
+        out = [L.DeviceBuffer(max(4 << log, 16)) for _ in range(4)]
+        L.call("tstwo_quotients_accumulate_samples", half_odds(log - 1), log, ptrs(d), n_cols, len(batches), L.u32x(off), L.u32x(cidx),
+               L.u32x(points), L.u32x(values), L.u32x((5, 6, 7, 8)), p4(out))
+        exp = orc.accumulate_quotients(half_odds(log - 1), log, cols, (5, 6, 7, 8), batches)
+        for k in range(4):
+            assert (host(out[k], 1 << log) == exp[k]).all(), (name, log, n_cols, k)
 
 
 def test_upload_async_from_registered_and_library_pinned_memory():

@@ -684,14 +684,18 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
     const size_t ptr_bytes = ((n_cols * sizeof(u32 *) + 63) / 64) * 64;
     const size_t bc_bytes = ((n_batches * sizeof(BatchConst) + 63) / 64) * 64;
     const size_t en_bytes = ((n_entries * sizeof(Entry) + 63) / 64) * 64;
-    // k >= 2 batches over ONE column list (the same columns in the same order in every batch) take the shared-load kernels,
-    // which read the list as two compact tables: per position the column pointer, per batch and position the coefficient
-    bool same_list = n_batches >= 2 && !knobs().quot_no_pair && batch_off[1] > batch_off[0];
-    const u32 per = same_list ? batch_off[1] - batch_off[0] : 0;
-    for (size_t bb = 1; same_list && bb < n_batches; bb++) {
-        same_list = batch_off[bb + 1] - batch_off[bb] == per;
-        for (size_t j = 0; same_list && j < per; j++) same_list = col_idx[batch_off[0] + j] == col_idx[batch_off[bb] + j];
-    }
+    // k >= 2 batches whose column lists overlap take the shared-load kernels, which read ONE list — the union of the batches'
+    // columns, in first-seen order — as two compact tables: per position the column pointer, per batch and position the
+    // coefficient (zero where a batch does not sample that column: it then adds nothing, and its a_j, b_j are not in the batch's
+    // A, B either; a column listed twice in a batch gets the sum of its coefficients).  Every column opened at the same k points is
+    // the case with no zeros; "every column at z, half of them also at z / g" is the common AIR shape with some.  Taken when the
+    // batches hold at least 1.4 entries per union column on average — below that the zero products cost more than the shared loads save.
+    std::vector<u32> ulist;
+    std::vector<int> upos(n_cols, -1);
+    for (size_t j = 0; j < n_entries; j++)
+        if (upos[col_idx[j]] < 0) { upos[col_idx[j]] = (int)ulist.size(); ulist.push_back(col_idx[j]); }
+    const u32 per = (u32)ulist.size();
+    const bool same_list = n_batches >= 2 && per > 0 && !knobs().quot_no_pair && 10 * n_entries >= 14 * (size_t)per;
     const size_t lp_bytes = same_list ? (((size_t)per * sizeof(u32 *) + 63) / 64) * 64 : 0;
     const size_t lc_bytes = same_list ? ((n_batches * (size_t)per * sizeof(qm31) + 63) / 64) * 64 : 0;
     std::vector<unsigned char> blob(ptr_bytes + bc_bytes + en_bytes + lp_bytes + lc_bytes + 64, 0);
@@ -723,9 +727,13 @@ int tstwo_quotients_accumulate_async(u32 half_initial, u32 log_size, const u32 *
     if (same_list) {
         const u32 **hlp = (const u32 **)(blob.data() + ptr_bytes + bc_bytes + en_bytes);
         qm31 *hlc = (qm31 *)(blob.data() + ptr_bytes + bc_bytes + en_bytes + lp_bytes);
-        for (size_t j = 0; j < per; j++) hlp[j] = cols[col_idx[batch_off[0] + j]];
+        for (size_t j = 0; j < per; j++) hlp[j] = cols[ulist[j]];
         for (size_t bb = 0; bb < n_batches; bb++)
-            for (size_t j = 0; j < per; j++) hlc[bb * per + j] = he[batch_off[bb] + j].c;
+            for (size_t j = batch_off[bb]; j < batch_off[bb + 1]; j++) {
+                qm31 &dst = hlc[bb * per + (size_t)upos[col_idx[j]]];          // (the blob is zero-initialised)
+                const host::Q sum = host::qadd({{dst.a, dst.b, dst.c, dst.d}}, {{he[j].c.a, he[j].c.b, he[j].c.c, he[j].c.d}});
+                dst = {sum.v[0], sum.v[1], sum.v[2], sum.v[3]};
+            }
     }
     int rc = ensure_scratch(blob.size());
     if (rc) return rc;
