@@ -561,7 +561,7 @@ def test_cfft_evaluate_extended_matches_extend_then_evaluate(log_poly, log_size)
         assert (out[0].download() == orc.cfft_evaluate(ext, log_size, half, otw, log_size - 1)).all()
 
 
-@pytest.mark.parametrize("log_poly,log_size,n_cols", [(20, 22, 8), (21, 22, 8), (21, 23, 4), (22, 23, 4), (20, 22, 5)])
+@pytest.mark.parametrize("log_poly,log_size,n_cols", [(20, 22, 8), (21, 22, 8), (21, 23, 4), (22, 23, 4), (20, 22, 5), (19, 21, 16), (20, 21, 9)])
 def test_cfft_wide_plans_on_the_2_15_tile_fused_and_out_of_place(log_poly, log_size, n_cols):
     """From 4 columns (n = 22) / 2 columns (n = 23) on, the default plan puts the strided pass on the 2^15-word tile (13 + 9 /
     13 + 10): the fused extension (k_cfft_a<false, K, EXT, 15>) against extend + evaluate, that evaluation against the oracle on

@@ -374,7 +374,9 @@ int plan_passes(u32 n, Pass *out, u32 kb = kMaxLogTileB, u32 ka_max = kMaxKA, u3
 
 // The default plan of a many-column transform (evaluate / interpolate / interpolate_to / evaluate_extended share it):
 //   n <= 13, n = 14      ONE pass on the contiguous tile (2^14 words at n = 14: 256 columns 16.4 against 21.2 us for 13 + 1);
-//   15 <= n <= 21        13 bottom layers + one strided pass on 2^14-word tiles;
+//   15 <= n <= 20        13 bottom layers + one strided pass on 2^14-word tiles (n = 19, 20 on the 2^15 tile measured equal or 1 % slower);
+//   n = 21               13 + 8 on the 2^15-word tile (512-byte rows) from two workgroups per CU on: 512 x 2^21 3.60 against 3.64 ms,
+//                        interpolate 3.78 against 3.85 (128 columns: 0.930 / 0.976 against 0.938 / 0.989);
 //   n = 22, 23           13 + 9 / 13 + 10 with the strided pass on the 2^15-word tile (k_cfft_a<., K, ., 15>: two virtual lanes per
 //                        lane, 256- / 128-byte rows) when the launch still has two workgroups per CU — round 4, same box, 256 x 2^22:
 //                        3.775 against 3.805 ms forward, 3.985 against 4.027 inverse; 128 x 2^23: 3.815 against 3.895 (14 + 9 on
@@ -388,7 +390,7 @@ inline PlanShape default_shape(u32 n, size_t n_cols) {
     const bool wide = n >= 15 && (((size_t)1 << (n - 15)) * n_cols) >= (size_t)2 * (size_t)ctx().n_cus;     // the 2^15 tile halves the workgroup count
     if (n == 24) return {14u, 10u, 15u};
     if (n == 23) return wide ? PlanShape{13u, 10u, 15u} : PlanShape{14u, kMaxKA, kLogTileA};
-    if (n == 22 && wide) return {13u, 9u, 15u};
+    if ((n == 22 || n == 21) && wide) return {13u, 9u, 15u};
     if (n == 14) return {14u, kMaxKA, kLogTileA};
     return {kMaxLogTileB, kMaxKA, kLogTileA};
 }
@@ -532,6 +534,7 @@ int launch_a_ext_k(u32 k, u32 logta, u32 *const *cols, const u32 *const *src, si
     if (logta == 15) {
         if (k == 10) return launch_a_ext<10, EXT, 15>(cols, src, n_cols, n, lo, tw_end);
         if (k == 9) return launch_a_ext<9, EXT, 15>(cols, src, n_cols, n, lo, tw_end);
+        if (k == 8) return launch_a_ext<8, EXT, 15>(cols, src, n_cols, n, lo, tw_end);
         return set_error(TSTWO_ERR_BAD_ARG, "cfft: unsupported pass shape");
     }
     switch (k) {
