@@ -343,6 +343,9 @@ def main():
 
     L.init(dev_index)
     if use_dist and collective == "rccl":
+        # one node by contract: RCCL's bootstrap sockets on the loopback interface (the container's other interfaces / host name
+        # may not resolve; the data path between the GPUs is xGMI peer-to-peer either way)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         ids = [None]
         if rank == 0:
             buf = (C.c_uint8 * 128)()
