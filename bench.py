@@ -472,6 +472,21 @@ def main():
     t_cfft = sum(e[0].elapsed_ms(e[1]) for e in evs)
     t_merkle = sum(e[1].elapsed_ms(e[2]) for e in evs)
 
+    if use_dist:
+        # every rank's roots must have arrived in rank order: compare the RCCL result with a gloo all-gather of the same roots
+        last = (step_no[0] - 1) & 1
+        got = roots_all[last].download(np.uint8, rec * world) if collective == "rccl" else roots_host[last]
+        mine = torch.from_numpy(np.frombuffer(my_roots(), dtype=np.uint8).copy())
+        ref = torch.zeros(rec * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(ref, mine)
+        assert bytes(got.tobytes()) == bytes(ref.numpy().tobytes()), "all-gathered roots differ from the ranks' own roots"
+        first = torch.from_numpy(np.frombuffer(gpu_roots_first, dtype=np.uint8).copy())
+        allfirst = torch.zeros(rec * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(allfirst, first)
+        tree_roots_first = bytes(allfirst.numpy().tobytes())
+    else:
+        tree_roots_first = gpu_roots_first
+
     # ---- the host boundary (never in `value`): what a caller pays who hands the trace over from HOST memory.
     #  (i) page-locked source (the caller's arrays registered with tstwo_host_register) -> tstwo_upload_async: one DMA per column;
     #  (ii) a whole step FROM HOST memory, pipelined: upload of tree k+1's columns on the copy stream under evaluate + commit of
@@ -532,21 +547,6 @@ def main():
                             "travel under evaluate + commit of tree k (tstwo_upload_fence in front of each tree)"}
         if not host_legs["roots_match_resident_step"]:
             raise SystemExit("bench.py: the step fed from host memory gave other Merkle roots than the resident step")
-
-    if use_dist:
-        # every rank's roots must have arrived in rank order: compare the RCCL result with a gloo all-gather of the same roots
-        last = (step_no[0] - 1) & 1
-        got = roots_all[last].download(np.uint8, rec * world) if collective == "rccl" else roots_host[last]
-        mine = torch.from_numpy(np.frombuffer(my_roots(), dtype=np.uint8).copy())
-        ref = torch.zeros(rec * world, dtype=torch.uint8)
-        dist.all_gather_into_tensor(ref, mine)
-        assert bytes(got.tobytes()) == bytes(ref.numpy().tobytes()), "all-gathered roots differ from the ranks' own roots"
-        first = torch.from_numpy(np.frombuffer(gpu_roots_first, dtype=np.uint8).copy())
-        allfirst = torch.zeros(rec * world, dtype=torch.uint8)
-        dist.all_gather_into_tensor(allfirst, first)
-        tree_roots_first = bytes(allfirst.numpy().tobytes())
-    else:
-        tree_roots_first = gpu_roots_first
 
     if rank == 0:
         steps = args.steps

@@ -66,3 +66,15 @@ def test_bench_gpus_2_starts_its_own_ranks_and_checks_every_root():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + ["--no-cpu"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
     assert _line(one.stdout)["gpu_roots"] == d["gpu_roots"]         # the same trees whatever N is
+
+
+def test_bench_rccl_collective_path_at_world_size_one():
+    """TSTWO_FORCE_DIST=1: the N > 1 code path (RCCL communicator through the C ABI, tstwo_allgather_async on the collective stream,
+    the gathered roots compared with the ranks' own) with a world of one on the one GPU — including the from-host legs, which run
+    after that comparison and must not disturb it (round 4: they once re-committed fresh columns in front of it)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TSTWO_FORCE_DIST"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 1 and d["root_match"] is True and d["host_boundary"]["roots_match_resident_step"] is True
