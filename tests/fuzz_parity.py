@@ -213,7 +213,7 @@ def case_quotients():
     for _ in range(n_batches):
         pt = _rand_secure_point()
         # one time in three every batch covers the same columns in the same order (each column opened at several points: with two
-        # batches that is the shared-load kernel, k_quotients8_pair)
+        # batches that is the shared-load kernel k_quotients8_multi<2>; three and more: k_quotients_rp)
         chosen = shared if shared is not None else rng.choice(n_cols, size=int(rng.integers(1, n_cols + 1)), replace=False)
         cv = [(int(c), _rq()) for c in chosen]
         batches_o.append((pt.x.tup(), pt.y.tup(), cv))
