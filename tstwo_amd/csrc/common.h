@@ -35,6 +35,9 @@ struct Context {
     int up_next = 0;
     // tstwo_upload_async: host -> device copies beside the kernels of `stream`, on kCopyStreams copy streams taken in turn (one
     // stream = one DMA engine at a time; two keep the link busy across the gap between consecutive copies)
+    u32 *seq_host = nullptr;             // wait_stream(): a sequence word in page-locked host memory mapped into the device ...
+    u32 *seq_dev = nullptr;              // ... as the one-lane signal kernel addresses it
+    u32 seq_next = 0;
     hipStream_t copy_stream[2] = {nullptr, nullptr};
     hipEvent_t copy_after = nullptr;     // recorded on `stream`, waited for by the copy stream: a copy never overtakes work enqueued before it
     hipEvent_t copy_done[2] = {nullptr, nullptr};   // recorded behind the last copy of each stream: tstwo_upload_fence makes `stream` wait for them
@@ -83,6 +86,7 @@ struct Knobs {
     bool quot_no_triple = false;       // TSTWO_QUOT_NO_TRIPLE: k batches over one column list as sweeps of 2 (+ 1) instead of 3 / 2 (A/B)
     // context.hip
     bool device_flag = false;          // TSTWO_DEVICE_FLAG: zero-inverse flag / result page in device memory
+    bool no_fast_wait = false;         // TSTWO_NO_FAST_WAIT: wait_stream() = hipStreamSynchronize (A/B of the polled sequence word)
 };
 #ifdef TSTWO_EXPERIMENTS
 const Knobs &knobs();
@@ -97,6 +101,14 @@ int set_error(int code, const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 int require_ready();
 int ensure_scratch(size_t bytes);
+// "Everything enqueued on the stream so far has completed" for the SMALL synchronous results of the boundary (a zero flag, a Merkle
+// root, eval_at_point's value, tstwo_download_many): hipStreamSynchronize costs 9.5 us on this stack whatever the work was, so a
+// one-lane kernel stores a sequence number into page-locked host memory behind the work and the host polls that word (bounded: after
+// ~100 us — work that long does not care about 9 us — it falls back to hipStreamSynchronize).  Results written by earlier kernels
+// into mapped host memory, or copied into page-locked memory by the stream, are visible before the number is (stream order, then
+// ordered bus writes).  Measured (profiles/r04_latency.txt): synchronous m31_batch_inverse of 2^20 12.9 against 16.5 us, a Merkle root 26.2
+// against 30.8; polling a HIP event instead (hipEventRecord + hipEventQuery) is slower than hipStreamSynchronize (17.3 us).
+int wait_stream();
 // reads the device error flag (synchronises the stream) and clears it
 int read_and_clear_flag(u32 *value);
 // Small device->host / host->device transfers through page-locked staging: a pageable hipMemcpy of a few bytes costs

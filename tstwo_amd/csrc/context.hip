@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -48,6 +49,7 @@ static Knobs read_knobs() {
     k.quot_no_triple = on("TSTWO_QUOT_NO_TRIPLE");
     k.quot_no_rowpair = on("TSTWO_QUOT_NO_ROWPAIR");
     k.device_flag = on("TSTWO_DEVICE_FLAG");
+    k.no_fast_wait = on("TSTWO_NO_FAST_WAIT");
     return k;
 }
 const Knobs &knobs() {
@@ -90,6 +92,27 @@ int ensure_scratch(size_t bytes) {
     c.scratch_bytes = want;
     return TSTWO_OK;
 }
+__global__ void k_signal(u32 *seq, u32 value) { *(volatile TSTWO_GLOBAL u32 *)seq = value; }
+int wait_stream() {
+    Context &c = g_ctx;
+    if (!c.seq_host || knobs().no_fast_wait) {
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        return TSTWO_OK;
+    }
+    const u32 want = ++c.seq_next;
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, c.stream, c.seq_dev, want);
+    if (hipGetLastError() != hipSuccess) {              // (e.g. a stream in capture mode: let the runtime report it)
+        TSTWO_HIP(hipStreamSynchronize(c.stream));
+        return TSTWO_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (__atomic_load_n(c.seq_host, __ATOMIC_ACQUIRE) == want) return TSTWO_OK;
+        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+    }
+    TSTWO_HIP(hipStreamSynchronize(c.stream));           // long-running work: block instead of burning a core
+    return TSTWO_OK;
+}
 int small_d2h(void *host_dst, const void *dev_src, size_t bytes) {
     Context &c = g_ctx;
     if (bytes == 0) return TSTWO_OK;
@@ -99,7 +122,7 @@ int small_d2h(void *host_dst, const void *dev_src, size_t bytes) {
         return TSTWO_OK;
     }
     TSTWO_HIP(hipMemcpyAsync(c.pinned, dev_src, bytes, hipMemcpyDeviceToHost, c.stream));
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    if (int rc = wait_stream()) return rc;
     memcpy(host_dst, c.pinned, bytes);
     return TSTWO_OK;
 }
@@ -109,7 +132,7 @@ void *result_target(size_t bytes) {
 }
 int result_wait(const void **host_view) {
     Context &c = g_ctx;
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    if (int rc = wait_stream()) return rc;
     *host_view = c.result_host;
     return TSTWO_OK;
 }
@@ -189,8 +212,8 @@ int fill_col_table(ColPtrs &out, const u32 *const *cols, size_t n_cols, int slot
 }
 int read_and_clear_flag(u32 *value) {
     Context &c = g_ctx;
-    if (c.flag_host) {          // the flag is host memory the kernels write through the bus: a synchronisation, no copy
-        TSTWO_HIP(hipStreamSynchronize(c.stream));
+    if (c.flag_host) {          // the flag is host memory the kernels write through the bus: a completion wait, no copy
+        if (int rc = wait_stream()) return rc;
         *value = *(volatile u32 *)c.flag_host;
         if (*value) *(volatile u32 *)c.flag_host = 0u;      // nothing is in flight on the stream: no kernel can race this store
         return TSTWO_OK;
@@ -366,6 +389,18 @@ int tstwo_init(int device) {
             if (h) (void)hipHostFree(h);
         }
     }
+    {   // sequence word of wait_stream()
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+            memset(h, 0, 64);
+            c.seq_host = (u32 *)h;
+            c.seq_dev = (u32 *)d;
+            c.seq_next = 0;
+        } else {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+        }
+    }
     if (hipHostMalloc(&c.up_ring, kUpSlots * kUpSlotBytes, hipHostMallocDefault) != hipSuccess) { c.up_ring = nullptr; (void)hipGetLastError(); }
     if (c.up_ring)
         for (int k = 0; k < kUpSlots; k++) TSTWO_HIP(hipEventCreateWithFlags(&c.up_done[k], hipEventDisableTiming));
@@ -391,6 +426,7 @@ int tstwo_shutdown(void) {
     if (c.result_host) (void)hipHostFree(c.result_host);
     c.result_host = c.result_dev = nullptr;
     if (c.pinned) (void)hipHostFree(c.pinned);
+    if (c.seq_host) (void)hipHostFree(c.seq_host);
     if (c.up_ring) {
         for (int k = 0; k < kUpSlots; k++) (void)hipEventDestroy(c.up_done[k]);
         (void)hipHostFree(c.up_ring);
@@ -697,7 +733,7 @@ int tstwo_download_many(const void *const *srcs, const size_t *n_bytes, size_t n
         if (k) hipLaunchKernelGGL(k_pack_pieces, dim3((unsigned)ceil_div((size_t)longest, (size_t)256), k), dim3(256), 0, c.stream, p, (u32 *)c.result_dev);
     }
     TSTWO_LAUNCH_CHECK();
-    TSTWO_HIP(hipStreamSynchronize(c.stream));
+    if (int rc = wait_stream()) return rc;
     memcpy(host_out, c.result_host, total);
     return TSTWO_OK;
 }

@@ -789,7 +789,7 @@ static int eval_at_point_impl(const u32 *const *coeffs, size_t n_cols, u32 log_s
         TSTWO_LAUNCH_CHECK();
         // one QM31 per column, contiguous (the last level has stride 1)
         if (host_dst) {
-            TSTWO_HIP(hipStreamSynchronize(c.stream));
+            if (int rcw = wait_stream()) return rcw;
             memcpy(out + 4 * col0, host_dst, g * sizeof(qm31));
         } else {
             rc = small_d2h(out + 4 * col0, src, g * sizeof(qm31));
